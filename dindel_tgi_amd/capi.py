@@ -1,0 +1,136 @@
+"""ctypes binding of the C ABI in include/dindel_hmm.h (libdindel_hmm.so).
+
+This is the test/bench harness' way into the product library — the same symbols a C++ host (the
+reference's DetInDel::computeLikelihoods, DInDel.cpp:1707-1739) binds directly.  There is no Python
+or CPU implementation behind it: if the shared library is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdindel_hmm.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u32p = C.POINTER(C.c_uint32)
+c_u8p = C.POINTER(C.c_uint8)
+c_i16p = C.POINTER(C.c_int16)
+c_f64p = C.POINTER(C.c_double)
+
+DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 64
+
+DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
+DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS = 0, 1, 2, 3
+
+
+class dd_params(C.Structure):
+    _fields_ = [("pError", C.c_double), ("pMut", C.c_double), ("pFirstgLO", C.c_double),
+                ("mapQualThreshold", C.c_double), ("checkBaseQualThreshold", C.c_double),
+                ("maxLengthDel", C.c_int32), ("padCover", C.c_int32), ("bMid", C.c_int32),
+                ("forceReadOnHaplotype", C.c_int32), ("mapUnmappedReads", C.c_int32)]
+
+    @classmethod
+    def from_dict(cls, d):
+        p = cls()
+        for k, v in d.items():
+            setattr(p, k, v)
+        return p
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def params_cli_defaults():
+    """DInDel.cpp:3937-3949 + 4122-4157 (the set production runs use)."""
+    return dd_params(5e-4, 1e-5, 0.01, 100.0, 0.95, 5, 2, -1, 0, 0)
+
+
+def params_struct_defaults():
+    """ObservationModel.hpp:39-64."""
+    return dd_params(1e-4, 1e-4, 0.01, 100.0, 0.95, 10, 5, -1, 0, 0)
+
+
+class dd_batch(C.Structure):
+    _fields_ = [("n_windows", C.c_int32),
+                ("win_hap_off", c_i32p), ("win_read_off", c_i32p), ("win_hap_start", c_u32p),
+                ("hap_seq_off", c_i32p), ("hap_seq", C.c_char_p), ("hap_var_off", c_i32p), ("hap_var", c_i32p),
+                ("read_seq_off", c_i32p), ("read_seq", C.c_char_p), ("read_qidx", c_u8p), ("read_mqidx", c_u8p),
+                ("read_start", c_u32p), ("read_flags", c_u8p),
+                ("n_qual", C.c_int32), ("qual_table", c_f64p),
+                ("n_mapq", C.c_int32), ("mapq_table", c_f64p)]
+
+
+RESULT_FIELDS = [("ll", c_f64p), ("llOn", c_f64p), ("llOff", c_f64p), ("mLogBQ", c_f64p),
+                 ("offHap", c_u8p), ("offHapHMQ", c_u8p),
+                 ("numIndels", c_i16p), ("numMismatch", c_i16p), ("nBQT", c_i16p), ("nmmBQT", c_i16p),
+                 ("nMMLeft", c_i16p), ("nMMRight", c_i16p), ("firstBase", c_i16p), ("lastBase", c_i16p),
+                 ("hpos", c_i16p), ("var_covered", c_u8p), ("status", c_i32p), ("onHap", c_u8p)]
+
+
+class dd_result(C.Structure):
+    _fields_ = RESULT_FIELDS
+
+
+class dd_sizes(C.Structure):
+    _fields_ = [("n_haps", C.c_int64), ("n_reads", C.c_int64), ("n_pairs", C.c_int64),
+                ("hap_bases", C.c_int64), ("read_bases", C.c_int64), ("hpos_len", C.c_int64),
+                ("var_cov_len", C.c_int64), ("cells", C.c_int64),
+                ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32)]
+
+
+class dd_device_batch(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("n_haps", C.c_int32), ("n_reads", C.c_int32),
+                ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32),
+                ("win_hap_off", C.c_void_p), ("win_read_off", C.c_void_p), ("win_hap_start", C.c_void_p),
+                ("hap_seq_off", C.c_void_p), ("hap_seq", C.c_void_p), ("hap_var_off", C.c_void_p), ("hap_var", C.c_void_p),
+                ("read_seq_off", C.c_void_p), ("read_seq", C.c_void_p), ("read_qidx", C.c_void_p), ("read_mqidx", C.c_void_p),
+                ("read_start", C.c_void_p), ("read_flags", C.c_void_p),
+                ("hap_window", C.c_void_p), ("win_pair_off", C.c_void_p), ("win_hpos_off", C.c_void_p),
+                ("win_varcov_off", C.c_void_p), ("tables", C.c_void_p),
+                ("n_qual", C.c_int32), ("n_mapq", C.c_int32)]
+
+
+class dd_device_result(C.Structure):
+    """dd_result with raw device addresses (same layout: every member is a pointer)."""
+    _fields_ = [(n, C.c_void_p) for n, _ in RESULT_FIELDS]
+
+
+EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
+           "dd_compute_likelihoods", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
+           "dd_launch_device", "dd_kernel_name", "dd_last_error", "dd_abi_version", "dd_device_count"]
+
+_lib = None
+
+
+def load():
+    """Load libdindel_hmm.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the likelihood path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.dd_params_struct_defaults.argtypes = [C.POINTER(dd_params)]
+    lib.dd_params_struct_defaults.restype = None
+    lib.dd_params_cli_defaults.argtypes = [C.POINTER(dd_params)]
+    lib.dd_params_cli_defaults.restype = None
+    lib.dd_batch_sizes.argtypes = [C.POINTER(dd_batch), C.POINTER(dd_sizes)]
+    lib.dd_batch_offsets.argtypes = [C.POINTER(dd_batch), c_i64p, c_i64p, c_i64p]
+    lib.dd_compute_likelihoods.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
+    lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
+    lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
+    lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]
+    lib.dd_workspace_bytes.restype = C.c_size_t
+    lib.dd_launch_device.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch), C.POINTER(dd_device_result),
+                                     C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dd_kernel_name.restype = C.c_char_p
+    lib.dd_last_error.restype = C.c_char_p
+    lib.dd_abi_version.restype = C.c_int
+    lib.dd_device_count.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().dd_last_error().decode()

@@ -1,0 +1,407 @@
+// capi.cpp — the C ABI of include/dindel_hmm.h: host-side tables, validation, device staging, launch.
+//
+// Host work here is O(bases) bookkeeping only (offsets, validation, log tables per distinct quality).
+// All likelihood arithmetic happens in hmm_kernel.hip; there is no CPU path for it in this library.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hmm_kernel.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(DD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+// ReadIndelErrorModel::getViterbiHPError — reference ReadIndelErrorModel.hpp:36-50
+double hp_error(int hpLen)
+{
+    static const double base[10] = {2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3};
+    int len = hpLen < 1 ? 1 : hpLen;
+    double pbe = (len <= 10) ? base[len - 1] : base[9] + 4.3e-4 * double(len - 10);
+    pbe *= double(hpLen);
+    if (pbe > 0.99) pbe = 0.99;
+    return pbe;
+}
+
+int pick_K(int max_hap_len)
+{
+    static const int ks[] = {1, 2, 3, 4, 6, 8, 12};
+    for (int k : ks)
+        if (64 * k >= max_hap_len + 2) return k;
+    return -1;
+}
+
+int pick_Dt(int D)
+{
+    if (D == 6) return 6;
+    if (D == 11) return 11;
+    return 12; // generic build: candidates y > D are switched off with -inf constants
+}
+
+uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// LDS carve-up for (K, Dt, Lmax); returns total dynamic LDS bytes per workgroup
+size_t lds_layout(int K, int Dt, int Lmax, int waves, ddk::KernelArgs &A)
+{
+    const uint32_t NP = 64u * K;
+    uint32_t o = 0;
+    o = up16(NP + 16);
+    A.lds_off_E = o;  o += up16((NP + 2) * 8);
+    A.lds_off_N = o;  o += up16((NP + 2) * 8);
+    A.lds_shared_bytes = o;
+    uint32_t wv = 0;
+    A.lds_off_A = wv;   wv += up16((2 * Dt + NP) * 8);
+    A.lds_off_I = wv;   wv += up16((NP + 2) * 8);
+    A.lds_off_rdE = wv; wv += up16(Lmax * 16);
+    A.lds_off_rdC = wv; wv += up16(Lmax);
+    A.lds_off_rdQ = wv; wv += up16(Lmax);
+    A.lds_off_ms = wv;  wv += up16(Lmax * 2);
+    A.lds_off_bt = wv;  wv += up16((uint32_t)Lmax * NP);
+    A.lds_wave_bytes = wv;
+    return (size_t)A.lds_shared_bytes + (size_t)waves * wv;
+}
+
+int check_params(const dd_params *p)
+{
+    if (!p) return fail(DD_ERR_INVALID, "null params");
+    if (p->mapUnmappedReads) return fail(DD_ERR_UNSUPPORTED, "mapUnmappedReads needs the Library insert-size pmf (out of scope)");
+    if (p->forceReadOnHaplotype) return fail(DD_ERR_UNSUPPORTED, "forceReadOnHaplotype is not on the production path (DInDel.cpp:1446 only)");
+    if (p->maxLengthDel < 0 || p->maxLengthDel > DD_MAX_LENGTH_DEL) return fail(DD_ERR_UNSUPPORTED, "maxLengthDel outside [0,11]");
+    if (!(p->pError > 0.0 && p->pError < 1.0)) return fail(DD_ERR_INVALID, "pError outside (0,1)");
+    return DD_SUCCESS;
+}
+
+struct DevBuf {
+    std::vector<void *> ptrs;
+    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    template <class T> int alloc(T **out, size_t n)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return DD_SUCCESS;
+    }
+    template <class T> int upload(const T **out, const T *src, size_t n)
+    {
+        T *d = nullptr;
+        int rc = alloc(&d, n);
+        if (rc) return rc;
+        if (n) {
+            hipError_t e = hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+        }
+        *out = d;
+        return DD_SUCCESS;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int dd_abi_version(void) { return DD_ABI_VERSION; }
+const char *dd_last_error(void) { return g_err.c_str(); }
+const char *dd_kernel_name(void) { return "dd_hmm_kernel"; }
+
+int dd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void dd_params_struct_defaults(dd_params *p)
+{   // ObservationModelParameters::setDefaultValues — reference ObservationModel.hpp:39-64
+    p->pError = 1e-4; p->pMut = 1e-4; p->pFirstgLO = 0.01; p->mapQualThreshold = 100.0;
+    p->checkBaseQualThreshold = 0.95; p->maxLengthDel = 10; p->padCover = 5; p->bMid = -1;
+    p->forceReadOnHaplotype = 0; p->mapUnmappedReads = 0;
+}
+
+void dd_params_cli_defaults(dd_params *p)
+{   // what main() installs — reference DInDel.cpp:3937-3949 with the option defaults at :4122-4157
+    dd_params_struct_defaults(p);
+    p->pError = 5e-4; p->pMut = 1e-5; p->maxLengthDel = 5; p->mapQualThreshold = 100.0; p->padCover = 2;
+}
+
+int dd_batch_sizes(const dd_batch *b, dd_sizes *out)
+{
+    if (!b || !out) return fail(DD_ERR_INVALID, "null argument");
+    if (b->n_windows < 0 || !b->win_hap_off || !b->win_read_off || !b->hap_seq_off || !b->read_seq_off)
+        return fail(DD_ERR_INVALID, "null offset array");
+    memset(out, 0, sizeof(*out));
+    const int W = b->n_windows;
+    out->n_haps = b->win_hap_off[W];
+    out->n_reads = b->win_read_off[W];
+    if (b->win_hap_off[0] != 0 || b->win_read_off[0] != 0 || b->hap_seq_off[0] != 0 || b->read_seq_off[0] != 0)
+        return fail(DD_ERR_INVALID, "offset arrays must start at 0");
+    for (int64_t h = 0; h < out->n_haps; h++) {
+        int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+        if (len < 0) return fail(DD_ERR_INVALID, "hap_seq_off not monotone");
+        if (len > out->max_hap_len) out->max_hap_len = len;
+    }
+    for (int64_t r = 0; r < out->n_reads; r++) {
+        int len = b->read_seq_off[r + 1] - b->read_seq_off[r];
+        if (len < 0) return fail(DD_ERR_INVALID, "read_seq_off not monotone");
+        if (len > out->max_read_len) out->max_read_len = len;
+    }
+    out->hap_bases = b->hap_seq_off[out->n_haps];
+    out->read_bases = b->read_seq_off[out->n_reads];
+    for (int w = 0; w < W; w++) {
+        int64_t H = b->win_hap_off[w + 1] - b->win_hap_off[w];
+        int64_t R = b->win_read_off[w + 1] - b->win_read_off[w];
+        if (H < 0 || R < 0) return fail(DD_ERR_INVALID, "window offsets not monotone");
+        int64_t SL = b->read_seq_off[b->win_read_off[w + 1]] - b->read_seq_off[b->win_read_off[w]];
+        int64_t SH = b->hap_seq_off[b->win_hap_off[w + 1]] - b->hap_seq_off[b->win_hap_off[w]];
+        int64_t nv = b->hap_var_off ? (b->hap_var_off[b->win_hap_off[w + 1]] - b->hap_var_off[b->win_hap_off[w]]) : 0;
+        out->n_pairs += H * R;
+        out->hpos_len += H * SL;
+        out->var_cov_len += nv * R;
+        out->cells += SH * SL;
+    }
+    return DD_SUCCESS;
+}
+
+int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off)
+{
+    if (!b) return fail(DD_ERR_INVALID, "null batch");
+    int64_t p = 0, hp = 0, vc = 0;
+    for (int w = 0; w < b->n_windows; w++) {
+        if (win_pair_off) win_pair_off[w] = p;
+        if (win_hpos_off) win_hpos_off[w] = hp;
+        if (win_varcov_off) win_varcov_off[w] = vc;
+        int64_t H = b->win_hap_off[w + 1] - b->win_hap_off[w];
+        int64_t R = b->win_read_off[w + 1] - b->win_read_off[w];
+        int64_t SL = b->read_seq_off[b->win_read_off[w + 1]] - b->read_seq_off[b->win_read_off[w]];
+        int64_t nv = b->hap_var_off ? (b->hap_var_off[b->win_hap_off[w + 1]] - b->hap_var_off[b->win_hap_off[w]]) : 0;
+        p += H * R; hp += H * SL; vc += nv * R;
+    }
+    if (win_pair_off) win_pair_off[b->n_windows] = p;
+    if (win_hpos_off) win_hpos_off[b->n_windows] = hp;
+    if (win_varcov_off) win_varcov_off[b->n_windows] = vc;
+    return DD_SUCCESS;
+}
+
+int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off)
+{
+    int rc = dd_batch_offsets(b, win_pair_off, win_hpos_off, win_varcov_off);
+    if (rc) return rc;
+    if (hap_window)
+        for (int w = 0; w < b->n_windows; w++)
+            for (int h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) hap_window[h] = w;
+    return DD_SUCCESS;
+}
+
+int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, const double *mapq_table, int n_mapq, double *out)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_qual < 0 || n_qual > DD_MAX_QUAL_TABLE || n_mapq < 0 || n_mapq > DD_MAX_QUAL_TABLE)
+        return fail(DD_ERR_INVALID, "quality table larger than 256 entries");
+    for (int i = 0; i < DD_TABLE_DOUBLES; i++) out[i] = 0.0;
+    // ObservationModelFBMaxErr::setupTransitionProbs — reference ObservationModelFB.cpp:1643-1667
+    const double logpInsgIns = -.5;
+    const double logpInsgNoIns = log(p->pError);
+    out[TC_LLL] = log(1.0 - p->pFirstgLO);
+    out[TC_LFL] = log(p->pFirstgLO);
+    out[TC_II] = logpInsgIns;
+    out[TC_NI] = log(1.0 - exp(logpInsgIns));
+    out[TC_IN] = logpInsgNoIns;
+    out[TC_NN] = log(1 - p->pError);
+    out[TC_EDEF] = log(1e-5);           // :1678
+    out[TC_NDEF] = log(1 - 1e-5);       // :1679
+    out[TC_BQT] = p->checkBaseQualThreshold;
+    // emissions — setupReadObservationPotentials, reference ObservationModelFB.cpp:226-234
+    for (int i = 0; i < n_qual; i++) {
+        const double rq = qual_table[i];
+        const double pr = rq * (1.0 - p->pMut);
+        out[T_QUAL + 4 * i + 0] = log(.25 + .75 * pr);
+        out[T_QUAL + 4 * i + 1] = log(.75 + 1e-10 - .75 * pr);
+        out[T_QUAL + 4 * i + 2] = log10(1.0 - rq);      // mLogBQ term, :1406
+        out[T_QUAL + 4 * i + 3] = rq;
+    }
+    // bMid prior — computeBMidPrior, reference ObservationModelFB.cpp:268-303 with pinsert == 0
+    for (int i = -1; i < n_mapq; i++) {
+        const double mapQual = (i < 0) ? (1.0 - 1e-10) : mapq_table[i];   // i<0: the "HMQ" prior of :1093
+        double mq = 1.0 - mapQual;
+        if (-10.0 * log10(mq) > p->mapQualThreshold) mq = pow(10.0, -p->mapQualThreshold / 10.0);
+        const double pOffFirst = mq;
+        const double pinsert = 0.0;
+        double *dst = (i < 0) ? &out[TC_HMQ] : &out[T_MAPQ + 4 * i];
+        for (int k = 0; k < 2; k++) {
+            const double logpIns = (k == 1) ? logpInsgNoIns : log(1.0 - exp(logpInsgNoIns));
+            dst[0 + k] = log(pOffFirst) + logpIns + pinsert;          // prior[i*numS+0]
+            dst[2 + k] = pinsert + log((1.0 - pOffFirst)) + logpIns;  // prior[i*numS+x], 1<=x<=hapSize
+        }
+    }
+    // homopolymer indel-error logs — reference ObservationModelFB.cpp:1683-1703
+    for (int len = 0; len < DD_HP_TABLE; len++) {
+        const double perr = hp_error(len < 1 ? 1 : len);
+        out[T_HP + 2 * len] = log(perr);
+        out[T_HP + 2 * len + 1] = log(1.0 - perr);
+    }
+    return T_END;
+}
+
+size_t dd_workspace_bytes(const dd_params *, const dd_device_batch *) { return 0; }
+
+int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *, size_t, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!b || !r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
+    if (b->n_haps <= 0 || b->n_reads <= 0) return DD_SUCCESS;
+    if (b->max_hap_len < 1 || b->max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype length outside [1,766]");
+    if (b->max_read_len < 1 || b->max_read_len > DD_MAX_READ_LEN) return fail(DD_ERR_UNSUPPORTED, "read length outside [1,1024]");
+    const int D = p->maxLengthDel + 1;
+    const int K = pick_K(b->max_hap_len);
+    const int Dt = pick_Dt(D);
+    if (K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
+
+    ddk::KernelArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_windows = b->n_windows; A.n_haps = b->n_haps; A.n_reads = b->n_reads;
+    A.win_hap_off = b->win_hap_off; A.win_read_off = b->win_read_off; A.win_hap_start = b->win_hap_start;
+    A.hap_seq_off = b->hap_seq_off; A.hap_seq = b->hap_seq; A.hap_var_off = b->hap_var_off; A.hap_var = b->hap_var;
+    A.read_seq_off = b->read_seq_off; A.read_seq = b->read_seq; A.read_qidx = b->read_qidx; A.read_mqidx = b->read_mqidx;
+    A.read_start = b->read_start; A.read_flags = b->read_flags;
+    A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
+    A.win_varcov_off = b->win_varcov_off; A.tables = b->tables;
+    A.out = *r;
+    A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
+    // 4 waves per workgroup when the back-pointer tiles fit; fewer for long reads x long haplotypes
+    int waves = DD_WAVES;
+    size_t lds = lds_layout(K, Dt, b->max_read_len, waves, A);
+    while (lds > 160u * 1024u && waves > 1) {
+        waves >>= 1;
+        lds = lds_layout(K, Dt, b->max_read_len, waves, A);
+    }
+    if (lds > 160u * 1024u)
+        return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length needs more than 160 KiB of LDS per wavefront");
+    // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
+    const int64_t target_blocks = 4096;
+    int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    int64_t max_split = (avg_reads + waves - 1) / waves;
+    if (max_split < 1) max_split = 1;
+    int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    A.n_split = (int32_t)split;
+    const int64_t grid = (int64_t)b->n_haps * split;
+    if (grid > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(ddk::launch_hmm(K, Dt, A, (unsigned)grid, waves, lds, st));
+    if (r->onHap && r->offHapHMQ) HIP_TRY(ddk::launch_onhap(A, st));
+    return DD_SUCCESS;
+}
+
+int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
+    dd_sizes sz;
+    rc = dd_batch_sizes(b, &sz);
+    if (rc) return rc;
+    if (sz.n_pairs == 0) return DD_SUCCESS;
+    // validate content
+    if (!b->hap_seq || !b->read_seq || !b->read_qidx || !b->read_mqidx || !b->read_start || !b->read_flags ||
+        !b->win_hap_start || !b->qual_table || !b->mapq_table)
+        return fail(DD_ERR_INVALID, "null input array");
+    if (b->n_qual < 1 || b->n_qual > DD_MAX_QUAL_TABLE || b->n_mapq < 1 || b->n_mapq > DD_MAX_QUAL_TABLE)
+        return fail(DD_ERR_INVALID, "quality tables must hold 1..256 entries");
+    for (int64_t h = 0; h < sz.n_haps; h++)
+        if (b->hap_seq_off[h + 1] - b->hap_seq_off[h] < 1) return fail(DD_ERR_INVALID, "empty haplotype");
+    for (int64_t i = 0; i < sz.hap_bases; i++) {
+        const char c = b->hap_seq[i];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N'))
+            return fail(DD_ERR_UNSUPPORTED, "haplotype bases must be A, C, G, T or N");
+    }
+    for (int64_t q = 0; q < sz.n_reads; q++) {
+        if (b->read_seq_off[q + 1] - b->read_seq_off[q] < 1) return fail(DD_ERR_INVALID, "empty read");
+        if (b->read_mqidx[q] >= b->n_mapq) return fail(DD_ERR_INVALID, "read_mqidx out of range");
+    }
+    for (int64_t i = 0; i < sz.read_bases; i++)
+        if (b->read_qidx[i] >= b->n_qual) return fail(DD_ERR_INVALID, "read_qidx out of range");
+    for (int i = 0; i < b->n_qual; i++)
+        if (!(b->qual_table[i] >= 0.0 && b->qual_table[i] <= 1.0)) return fail(DD_ERR_INVALID, "base quality outside [0,1]");
+    for (int i = 0; i < b->n_mapq; i++)
+        if (!(b->mapq_table[i] >= 0.0 && b->mapq_table[i] < 1.0)) return fail(DD_ERR_INVALID, "mapping quality outside [0,1)");
+    if (sz.max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766");
+    if (sz.max_read_len > DD_MAX_READ_LEN) return fail(DD_ERR_UNSUPPORTED, "read longer than 1024");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DD_ERR_NO_DEVICE, "no HIP device: the likelihood path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(DD_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    const int W = b->n_windows;
+    std::vector<int32_t> hap_window((size_t)sz.n_haps);
+    std::vector<int64_t> pair_off(W + 1), hpos_off(W + 1), vc_off(W + 1);
+    dd_build_index(b, hap_window.data(), pair_off.data(), hpos_off.data(), vc_off.data());
+    std::vector<double> tables(DD_TABLE_DOUBLES);
+    rc = dd_build_tables(p, b->qual_table, b->n_qual, b->mapq_table, b->n_mapq, tables.data());
+    if (rc < 0) return rc;
+
+    DevBuf dev;
+    dd_device_batch db;
+    memset(&db, 0, sizeof(db));
+    db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
+    db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
+    db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
+#define UP(field, n) if ((rc = dev.upload(&db.field, b->field, (size_t)(n)))) return rc
+    UP(win_hap_off, W + 1); UP(win_read_off, W + 1); UP(win_hap_start, W);
+    UP(hap_seq_off, sz.n_haps + 1); UP(hap_seq, sz.hap_bases);
+    UP(read_seq_off, sz.n_reads + 1); UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases);
+    UP(read_mqidx, sz.n_reads); UP(read_start, sz.n_reads); UP(read_flags, sz.n_reads);
+#undef UP
+    if (b->hap_var_off) {
+        if ((rc = dev.upload(&db.hap_var_off, b->hap_var_off, (size_t)sz.n_haps + 1))) return rc;
+        if ((rc = dev.upload(&db.hap_var, b->hap_var, (size_t)2 * b->hap_var_off[sz.n_haps]))) return rc;
+    }
+    if ((rc = dev.upload(&db.hap_window, (const int32_t *)hap_window.data(), hap_window.size()))) return rc;
+    if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
+    if ((rc = dev.upload(&db.win_hpos_off, (const int64_t *)hpos_off.data(), hpos_off.size()))) return rc;
+    if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
+    if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
+
+    dd_result dr;
+    memset(&dr, 0, sizeof(dr));
+    const size_t np = (size_t)sz.n_pairs;
+#define OUT(field, n) if (r->field && (rc = dev.alloc(&dr.field, (size_t)(n)))) return rc
+    OUT(ll, np); OUT(llOn, np); OUT(llOff, np); OUT(mLogBQ, np); OUT(offHap, np); OUT(numIndels, np);
+    OUT(numMismatch, np); OUT(nBQT, np); OUT(nmmBQT, np); OUT(nMMLeft, np); OUT(nMMRight, np); OUT(firstBase, np);
+    OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT(status, np); OUT(onHap, sz.n_reads);
+#undef OUT
+    if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
+
+    rc = dd_launch_device(p, &db, &dr, nullptr, 0, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+#define DOWN(field, n) if (r->field && (n)) HIP_TRY(hipMemcpy(r->field, dr.field, (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost))
+    DOWN(ll, np); DOWN(llOn, np); DOWN(llOff, np); DOWN(mLogBQ, np); DOWN(offHap, np); DOWN(offHapHMQ, np);
+    DOWN(numIndels, np); DOWN(numMismatch, np); DOWN(nBQT, np); DOWN(nmmBQT, np); DOWN(nMMLeft, np); DOWN(nMMRight, np);
+    DOWN(firstBase, np); DOWN(lastBase, np); DOWN(hpos, sz.hpos_len); DOWN(var_covered, sz.var_cov_len);
+    DOWN(status, np); DOWN(onHap, sz.n_reads);
+#undef DOWN
+    return DD_SUCCESS;
+}
+
+} // extern "C"

@@ -1,0 +1,60 @@
+// hmm_kernel.h — kernel argument block, table layout and launchers shared by hmm_kernel.hip and capi.cpp.
+#ifndef DD_HMM_KERNEL_H
+#define DD_HMM_KERNEL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dindel_hmm.h"
+
+#define DD_WAVES 4   /* max wavefronts per workgroup: one per SIMD of a CU, one pair in flight per wave */
+
+/* layout of the host-built table block (dd_build_tables) */
+enum {
+    TC_LLL = 0,   /* log(1-pFirstgLO)            ObservationModelFB.cpp:1643 */
+    TC_LFL = 1,   /* log(pFirstgLO)              :1644 */
+    TC_II = 2,    /* logpInsgIns = -0.5          :1664 */
+    TC_NI = 3,    /* log(1-exp(logpInsgIns))     :1665 */
+    TC_IN = 4,    /* log(pError)                 :1666 */
+    TC_NN = 5,    /* log(1-pError)               :1667 */
+    TC_EDEF = 6,  /* log(1e-5)                   :1678 */
+    TC_NDEF = 7,  /* log(1-1e-5)                 :1679 */
+    TC_BQT = 8,   /* checkBaseQualThreshold */
+    TC_HMQ = 12,  /* 4 doubles: bMid prior for mapQual = 1-1e-10 (:1093): off/noins, off/ins, on/noins, on/ins */
+    T_QUAL = 32,                          /* 4 per quality: eq, uq (:232-234), log10(1-q) (:1406), q */
+    T_MAPQ = T_QUAL + 4 * DD_MAX_QUAL_TABLE, /* 4 per mapping quality: prior off/noins, off/ins, on/noins, on/ins (:296-303) */
+    T_HP = T_MAPQ + 4 * DD_MAX_QUAL_TABLE,   /* 2 per run length: log(perr(len)), log(1-perr(len)) (ReadIndelErrorModel.hpp:36-50) */
+    T_END = T_HP + 2 * DD_HP_TABLE
+};
+
+namespace ddk {
+
+struct KernelArgs {
+    /* batch (device pointers) */
+    int32_t n_windows, n_haps, n_reads;
+    const int32_t *win_hap_off, *win_read_off;
+    const uint32_t *win_hap_start;
+    const int32_t *hap_seq_off;
+    const char *hap_seq;
+    const int32_t *hap_var_off, *hap_var;
+    const int32_t *read_seq_off;
+    const char *read_seq;
+    const uint8_t *read_qidx, *read_mqidx;
+    const uint32_t *read_start;
+    const uint8_t *read_flags;
+    const int32_t *hap_window;
+    const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
+    const double *tables;
+    dd_result out;
+    /* params */
+    int32_t D, maxLengthDel, padCover, bMid;
+    /* launch geometry */
+    int32_t n_split;
+    /* LDS layout (bytes) */
+    uint32_t lds_off_E, lds_off_N, lds_shared_bytes, lds_wave_bytes;
+    uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
+};
+
+hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
+hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
+
+} // namespace ddk
+#endif

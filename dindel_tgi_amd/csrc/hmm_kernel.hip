@@ -1,0 +1,661 @@
+// hmm_kernel.hip — gfx950 (CDNA4) kernels for Dindel's read x candidate-haplotype HMM likelihood.
+//
+// Replaces, for a whole batch of windows, the double loop of DetInDel::computeLikelihoods
+// (reference DInDel.cpp:1715-1737) and everything ObservationModelFBMaxErr::calcLikelihood does per
+// (haplotype, read) pair (reference ObservationModelFB.cpp:1057-1165, 1351-1475, 1641-1829).
+//
+// Mapping to the machine (NOT a translation of the reference's per-pair heap arrays):
+//   * one workgroup = one candidate haplotype (x a slice of its window's reads); the haplotype's
+//     state codes and per-position indel-error logs are built once in LDS and turned into per-lane
+//     register constants, then reused for every read the workgroup's wavefronts process;
+//   * one wavefront = one (read, haplotype) pair at a time; lane l owns the K consecutive hap
+//     positions x = l*K .. l*K+K-1 (both the "on base x" and the "inserted at x" state), so a
+//     64-wide wave covers numS = Hs+2 <= 64*K positions and one read base (one HMM slice) is one
+//     sweep of straight-line fp64 add / compare / select code;
+//   * neighbour states (the <= D = maxLengthDel+1 jump candidates) come from a wave-private LDS row;
+//     single buffer, no barrier: DS operations of one wave execute in order;
+//   * back-pointers are one byte per (read base, position) in wave-private LDS, the traceback walks
+//     them there, and hpos[] / QC counters are produced lane-parallel over read bases;
+//   * no transcendental is evaluated on the device: every log() the reference takes is tabulated on
+//     the host with libm (tables.cpp) so results cannot differ from glibc's.
+//
+// Arithmetic: fp64, every sum in the reference's written term order (fp64 + is not associative and
+// updateMax has a 1e-10 hysteresis, ObservationModelFB.cpp:877-888).  No MFMA: this is a max-plus
+// recurrence, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hmm_kernel.h"
+
+namespace ddk {
+
+#define DD_EPS 1e-10
+#define NEG_INF (-__builtin_huge_val())
+
+__device__ __forceinline__ int base_code(unsigned char ch)
+{
+    // A C G T -> 0..3, N -> 4, anything else -> 5 (reads only; haplotypes are validated to ACGTN)
+    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : 5;
+}
+
+// hap[y]=='N' || hap[y]==nuc  (ObservationModelFB.cpp:246); state code 4 = 'N' or LO/RO (always eq)
+__device__ __forceinline__ bool code_match(int scode, int rcol) { return scode == 4 || scode == rcol; }
+
+// exact ObservationModelFBMax::updateMax (ObservationModelFB.cpp:877-888) for the few special states
+__device__ __forceinline__ void update_max(double &dest, int &idx, int &code, double v, int newIdx, int newCode)
+{
+    if (v > dest + DD_EPS) { dest = v; idx = newIdx; code = newCode; }
+    else if (v >= dest && v <= dest + 1e-5 && idx > newIdx) { dest = v; idx = newIdx; code = newCode; }
+}
+
+template <int K, int D>
+struct LaneConst {
+    double lpn[K];        // Nn[x]               (Dec: logProbNoError[x])
+    double eIn[K];        // E[x]                (Dec: insertion-open into x)
+    double lpDec[K][D];   // y=1: Nn[x]; y>=2: E[x]+(y-1)*II
+    double cInc[K][D];    // (lp_y(src)+Nn[src]) for src=x+y
+    double eInc[K];       // E[x+1]              (Inc: insertion-open)
+    uint64_t mDec[K];     // bit c*D+(y-1): obs(state x-y) == eq for read column c
+    uint64_t mInc[K];     // bit c*D+(y-1): obs(state x+y) == eq for read column c
+    uint32_t mOwn[K];     // bit c: obs(state x) == eq
+};
+
+template <int K, int D>
+__global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 4, 2 or 1 waves (host picks what fits LDS)
+
+    const int g = blockIdx.x / P.n_split;          // global haplotype index
+    const int split = blockIdx.x - g * P.n_split;
+    const int w = P.hap_window[g];
+    const int h0 = P.win_hap_off[w];
+    const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1];
+    const int R = r1 - r0;
+    const int hs_off = P.hap_seq_off[g];
+    const int Hs = P.hap_seq_off[g + 1] - hs_off;
+    const int numS = Hs + 2, RO = Hs + 1;
+    const uint32_t hapStart = P.win_hap_start[w];
+    const int NP = 64 * K;
+    const int Dr = P.D;                             // real D (== D unless the generic D=12 build is used)
+
+    const double *T = P.tables;
+    const double lLL = T[TC_LLL], lFL = T[TC_LFL], II = T[TC_II], NI = T[TC_NI], NN = T[TC_NN];
+
+    // ---------------- shared (per haplotype) region ----------------
+    unsigned char *sc = smem;                                   // [NP+16] state codes
+    double *shE = reinterpret_cast<double *>(smem + P.lds_off_E);  // [NP+2]
+    double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+2]
+    // ---------------- wave-private region ----------------
+    unsigned char *wbase = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
+    double *bufA = reinterpret_cast<double *>(wbase + P.lds_off_A);       // [D + NP + D]   index s -> bufA[D+s]
+    double *bufI = reinterpret_cast<double *>(wbase + P.lds_off_I);       // [1 + NP + 1]   index s -> bufI[1+s]
+    double *rdE = reinterpret_cast<double *>(wbase + P.lds_off_rdE);      // [Lmax][2]  eq, uq per read base
+    unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
+    unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
+    int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
+    unsigned char *bt = wbase + P.lds_off_bt;                              // [Lmax][NP] back-pointers
+    double *contrib = reinterpret_cast<double *>(wbase + P.lds_off_bt);   // aliases bt after traceback
+
+    const bool hap_ok = (P.maxLengthDel <= Hs);     // else "hapSize error." (ObservationModelFB.cpp:47)
+
+    // ---- per-haplotype setup: state codes + homopolymer indel-error logs (setupTransitionProbs :1675-1703)
+    for (int s = tid; s < NP + 16; s += nthr) {
+        int code = 6;                                // padded state: matches nothing
+        if (s == 0 || s == RO) code = 4;
+        else if (s < RO) code = base_code((unsigned char)P.hap_seq[hs_off + s - 1]);
+        sc[s] = (unsigned char)code;
+    }
+    for (int s = tid; s < NP + 2; s += nthr) {
+        shE[s] = T[TC_EDEF];
+        shN[s] = T[TC_NDEF];
+    }
+    __syncthreads();
+    if (tid == 0) { shE[1] = T[T_HP + 2 * 1]; shN[1] = T[T_HP + 2 * 1 + 1]; }
+    __syncthreads();
+    for (int b = 1 + tid; b < Hs; b += nthr) {
+        const char *hp = P.hap_seq + hs_off;
+        if (hp[b] != hp[b - 1]) {
+            int len = 1;
+            while (b - 1 - len >= 0 && hp[b - 1 - len] == hp[b - 1]) len++;
+            int li = len < DD_HP_TABLE - 1 ? len : DD_HP_TABLE - 1;
+            shE[b] = T[T_HP + 2 * li];
+            shN[b] = T[T_HP + 2 * li + 1];
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && Hs >= 1) {
+        const char *hp = P.hap_seq + hs_off;
+        int len = 1;
+        while (Hs - 1 - len >= 0 && hp[Hs - 1 - len] == hp[Hs - 1]) len++;
+        int li = len < DD_HP_TABLE - 1 ? len : DD_HP_TABLE - 1;
+        shE[Hs - 1] = T[T_HP + 2 * li];              // index hapSize-1, as the reference writes it (:1702)
+        shN[Hs - 1] = T[T_HP + 2 * li + 1];
+    }
+    __syncthreads();
+
+    // ---- per-lane register constants for this haplotype ----
+    LaneConst<K, D> C;
+    const int x0 = lane * K;
+    const int laneRO = RO / K, kRO = RO - laneRO * K;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int x = x0 + k;
+        const bool valid = x < numS;
+        const double Ek = valid ? shE[x] : NEG_INF;
+        const double Nk = valid ? shN[x] : NEG_INF;
+        C.lpn[k] = Nk;
+        C.eIn[k] = Ek;
+        uint64_t md = 0, mi = 0;
+#pragma unroll
+        for (int y = 1; y <= D; y++) {
+            C.lpDec[k][y - 1] = (y > Dr) ? NEG_INF : (y == 1 ? Nk : Ek + (double)(y - 1) * II);
+            const int src = x + y;
+            double c = NEG_INF;
+            if (src <= RO && y <= Dr) {
+                const double Es = shE[src], Ns = shN[src];
+                const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
+                c = lp + Ns;
+            }
+            C.cInc[k][y - 1] = c;
+#pragma unroll
+            for (int col = 0; col < 5; col++) {
+                if (x - y >= 0 && code_match(sc[x - y], col)) md |= 1ull << (col * D + (y - 1));
+                if (src <= RO && code_match(sc[src], col)) mi |= 1ull << (col * D + (y - 1));
+            }
+        }
+        C.mDec[k] = md;
+        C.mInc[k] = mi;
+        uint32_t mo = 0;
+#pragma unroll
+        for (int col = 0; col < 5; col++)
+            if (valid && code_match(sc[x], col)) mo |= 1u << col;
+        C.mOwn[k] = mo;
+        C.eInc[k] = (x + 1 <= RO) ? shE[x + 1] : NEG_INF;
+    }
+    const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
+
+    // pads of the wave-private rows: written once, never touched again
+    if (lane < D) { bufA[lane] = NEG_INF; bufA[D + NP + lane] = NEG_INF; }
+    if (lane == 0) { bufI[0] = NEG_INF; bufI[1 + NP] = NEG_INF; }
+
+    const int64_t pair_base = P.win_pair_off[w] + (int64_t)(g - h0) * R;
+    const int rs_base = P.read_seq_off[r0];
+    const int64_t SL = (int64_t)P.read_seq_off[r1] - rs_base;
+    const int64_t hpos_base = P.win_hpos_off[w] + (int64_t)(g - h0) * SL;
+    const int nv = P.hap_var_off ? (P.hap_var_off[g + 1] - P.hap_var_off[g]) : 0;
+
+    // ======================= loop over this wave's reads =======================
+    for (int ri = split * nwav + wave; ri < R; ri += P.n_split * nwav) {
+        const int r = r0 + ri;
+        const int64_t pair = pair_base + ri;
+        const int so = P.read_seq_off[r];
+        const int L = P.read_seq_off[r + 1] - so;
+
+        if (!hap_ok) {
+            if (lane == 0) {
+                P.out.status[pair] = DD_PAIR_HAPSIZE;
+                P.out.ll[pair] = 0.0;
+            }
+            continue;
+        }
+
+        // ---- bMid: ObservationModelFB::Init (ObservationModelFB.cpp:51-99) ----
+        int bMid;
+        {
+            const uint32_t hapEnd = hapStart + (uint32_t)Hs;
+            const uint32_t mReadStart = P.read_start[r];
+            const uint32_t readEnd = mReadStart + (uint32_t)L - 1u;
+            if ((P.read_flags[r] & 1) || mReadStart > hapEnd || readEnd < hapStart) {
+                bMid = L / 2;
+            } else {
+                const uint32_t olStart = (hapStart > mReadStart) ? hapStart : mReadStart;
+                const uint32_t olEnd = (hapEnd > readEnd) ? readEnd : hapEnd;
+                const int mid = ((int)olEnd - (int)olStart) / 2 + (int)olStart;
+                bMid = mid - (int)mReadStart;
+            }
+            if (P.bMid != -1) bMid = P.bMid;
+            if (bMid < 0) bMid = 0;
+            if (bMid >= L) bMid = L - 1;
+        }
+
+        // ---- stage the read: base codes + emission logs (setupReadObservationPotentials :220-252) ----
+        for (int b = lane; b < L; b += 64) {
+            const int qi = P.read_qidx[so + b];
+            rdC[b] = (unsigned char)base_code((unsigned char)P.read_seq[so + b]);
+            rdQ[b] = (unsigned char)qi;
+            rdE[2 * b] = T[T_QUAL + 4 * qi];
+            rdE[2 * b + 1] = T[T_QUAL + 4 * qi + 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        double a[K], in[K];           // current slice: "on base x" and "inserted at x"
+        // ================= left -> middle: passMessageTwoDec for b = 1..bMid (:1573-1575, :1775-1829)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool valid = (x0 + k) < numS;
+            a[k] = valid ? 0.0 : NEG_INF;      // alpha[0][*] = 0 (:335-338)
+            in[k] = valid ? 0.0 : NEG_INF;
+        }
+        for (int b = 1; b <= bMid; b++) {
+            // publish slice b-1 for the neighbours
+#pragma unroll
+            for (int k = 0; k < K; k++) { bufA[D + x0 + k] = a[k]; bufI[1 + x0 + k] = in[k]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
+            const int col = rdC[b - 1] > 4 ? 4 : rdC[b - 1];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double v[D + K];
+#pragma unroll
+            for (int j = 0; j < D; j++) v[j] = bufA[x0 + j];       // A[x0-D+j]
+#pragma unroll
+            for (int k = 0; k < K; k++) v[D + k] = a[k];
+            const double im1 = bufI[x0];                            // I[x0-1]
+            double na[K], ni[K];
+            unsigned btb[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t mb = (uint32_t)(C.mDec[k] >> (col * D));
+                double best = ((((mb & 1u) ? eq : uq) + C.lpDec[k][0]) + v[D + k - 1]) + C.lpn[k];
+                unsigned ch = 1;
+#pragma unroll
+                for (int y = 2; y <= D; y++) {
+                    const double o = ((mb >> (y - 1)) & 1u) ? eq : uq;
+                    const double val = ((o + C.lpDec[k][y - 1]) + v[D + k - y]) + C.lpn[k];
+                    const bool take = val >= best;                 // newIdx < destIdx: branch 2 of updateMax
+                    best = take ? val : best;
+                    ch = take ? (unsigned)y : ch;
+                }
+                {
+                    const double ip = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
+                    const double val = (eq + ip) + C.eIn[k];       // from inserted state numS+x-1 (:1807-1811)
+                    const bool take = val > best + DD_EPS;
+                    best = take ? val : best;
+                    ch = take ? 0u : ch;
+                }
+                na[k] = best;
+                const double d = (eq + in[k]) + II;                // (:1816-1820)
+                const double o = ((C.mOwn[k] >> col) & 1u) ? eq : uq;
+                const double val = (o + a[k]) + NI;                // (:1823-1826)
+                const bool take = val >= d;
+                ni[k] = take ? val : d;
+                btb[k] = ch | (take ? 16u : 0u);
+            }
+            if (lane == 0) {                                        // x = 0  (:1798-1799, :1816)
+                na[0] = (eq + a[0]) + NN;
+                ni[0] = (eq + in[0]) + II;
+                btb[0] = 0;
+            }
+            if (lane == laneRO) {                                   // x = RO (:1780-1782, :1804-1805)
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (k == kRO) {
+                        const double aHs = v[D + k - 1];
+                        const double iHs = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
+                        const uint32_t mb = (uint32_t)(C.mDec[k] >> (col * D));
+                        const double oHs = (mb & 1u) ? eq : uq;
+                        double best = NEG_INF;
+                        int idx = 0, code = 0;
+                        update_max(best, idx, code, ((eq + a[k]) + lLL) + NN, RO, 0);
+                        update_max(best, idx, code, ((oHs + aHs) + lFL) + NN, Hs, 1);
+                        update_max(best, idx, code, ((eq + in[k]) + lLL) + E_RO, numS + RO, 2);
+                        update_max(best, idx, code, ((eq + iHs) + lFL) + E_Hs, numS + Hs, 3);
+                        na[k] = best;
+                        btb[k] = (btb[k] & 16u) | (unsigned)code;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                a[k] = na[k];
+                in[k] = ni[k];
+                bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];
+            }
+        }
+        double al_a[K], al_i[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { al_a[k] = a[k]; al_i[k] = in[k]; }
+
+        // ================= right -> middle: passMessageTwoInc for b = L-1..bMid+1 (:1576-1578, :1715-1773)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool valid = (x0 + k) < numS;
+            a[k] = valid ? 0.0 : NEG_INF;      // beta[L-1][*] = 0
+            in[k] = valid ? 0.0 : NEG_INF;
+        }
+        for (int b = L - 1; b > bMid; b--) {
+#pragma unroll
+            for (int k = 0; k < K; k++) bufA[D + x0 + k] = a[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
+            const int col = rdC[b] > 4 ? 4 : rdC[b];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double v[D + K];
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = a[k];
+#pragma unroll
+            for (int j = 0; j < D; j++) v[K + j] = bufA[D + x0 + K + j];   // B[x0+K+j]
+            double na[K], ni[K];
+            unsigned btb[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t mb = (uint32_t)(C.mInc[k] >> (col * D));
+                double best = (C.cInc[k][0] + v[k + 1]) + ((mb & 1u) ? eq : uq);
+                unsigned ch = 1;
+#pragma unroll
+                for (int y = 2; y <= D; y++) {
+                    const double o = ((mb >> (y - 1)) & 1u) ? eq : uq;
+                    const double val = (C.cInc[k][y - 1] + v[k + y]) + o;  // lp+lpn+beta+obs (:1735)
+                    const bool take = val > best + DD_EPS;                  // newIdx > destIdx: branch 1 only
+                    best = take ? val : best;
+                    ch = take ? (unsigned)y : ch;
+                }
+                {
+                    const double val = (eq + in[k]) + C.eInc[k];            // to inserted state numS+x (:1746-1749)
+                    const bool take = val > best + DD_EPS;
+                    best = take ? val : best;
+                    ch = take ? 0u : ch;
+                }
+                na[k] = best;
+                const double d = (eq + in[k]) + II;                         // (:1754-1758)
+                const double val = (((mb & 1u) ? eq : uq) + v[k + 1]) + NI; // src = x+1 (:1763-1767)
+                const bool take = val >= d;
+                ni[k] = take ? val : d;
+                btb[k] = ch | (take ? 16u : 0u);
+            }
+            if (lane == 0) {                                                 // x = 0 (:1720-1722, :1746-1749, :1762)
+                const uint32_t mb = (uint32_t)(C.mInc[0] >> (col * D));
+                double best = NEG_INF;
+                int idx = 0, code = 0;
+                update_max(best, idx, code, ((eq + a[0]) + lLL) + NN, 0, 0);
+                update_max(best, idx, code, ((((mb & 1u) ? eq : uq) + v[1]) + lFL) + NN, 1, 1);
+                update_max(best, idx, code, (eq + in[0]) + E_1, numS + 0, 2);
+                na[0] = best;
+                const double d = (eq + in[0]) + II;
+                const double val = (eq + a[0]) + NI;
+                const bool take = val >= d;
+                ni[0] = take ? val : d;
+                btb[0] = (unsigned)code | (take ? 16u : 0u);
+            }
+            if (lane == laneRO) {                                            // x = RO (:1741-1742, :1750, :1763-1767)
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (k == kRO) {
+                        double best = NEG_INF;
+                        int idx = 0, code = 0;
+                        update_max(best, idx, code, (eq + a[k]) + Nn_RO, RO, 0);
+                        update_max(best, idx, code, (eq + in[k]), numS + RO, 1);
+                        na[k] = best;
+                        const double d = (eq + in[k]) + II;
+                        const double val = (eq + a[k]) + NI;
+                        const bool take = val >= d;
+                        ni[k] = take ? val : d;
+                        btb[k] = (unsigned)code | (take ? 16u : 0u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                a[k] = na[k];
+                in[k] = ni[k];
+                bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];    // btb[b-1] stored at row b
+            }
+        }
+
+        // ================= join at bMid: calcLikelihoodFromLastSlice (:1075-1144) + computeBMidPrior (:268-305)
+        double ll = NEG_INF, llHMQ = NEG_INF, llOff = NEG_INF, llOn = NEG_INF;
+        int mapRMQ = 0, mapHMQ = 0;
+        {
+            const double eq = rdE[2 * bMid], uq = rdE[2 * bMid + 1];
+            const int col = rdC[bMid] > 4 ? 4 : rdC[bMid];
+            const int mqi = P.read_mqidx[r];
+            const double prOff0 = T[T_MAPQ + 4 * mqi + 0], prOff1 = T[T_MAPQ + 4 * mqi + 1];
+            const double prOn0 = T[T_MAPQ + 4 * mqi + 2], prOn1 = T[T_MAPQ + 4 * mqi + 3];
+            const double hqOff0 = T[TC_HMQ + 0], hqOff1 = T[TC_HMQ + 1], hqOn0 = T[TC_HMQ + 2], hqOn1 = T[TC_HMQ + 3];
+            double *vA = bufA + D;                 // [NP] states 0..numS-1   (the row buffers are free now)
+            double *vI = bufI + 1;                 // [NP] inserted states
+            double baseA[K], baseI[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int x = x0 + k;
+                const double o = ((C.mOwn[k] >> col) & 1u) ? eq : uq;
+                baseA[k] = (al_a[k] + o) + a[k];               // alpha + obs + beta (:1098)
+                baseI[k] = (al_i[k] + eq) + in[k];
+                vA[x] = baseA[k] + ((x == 0) ? prOff0 : (x == RO ? -100.0 : prOn0));
+                vI[x] = baseI[k] + ((x == 0) ? prOff1 : (x == RO ? -100.0 : prOn1));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // sequential scan in state order, every lane redundantly (wave-uniform): identical to :1096-1117
+            for (int s = 0; s < 2 * numS; s++) {
+                const int x = s < numS ? s : s - numS;
+                const double v = s < numS ? vA[x] : vI[x];
+                if (v > ll + DD_EPS) { ll = v; mapRMQ = s; }
+                if (x == 0) { if (v > llOff) llOff = v; }
+                else if (x != RO) { if (v > llOn) llOn = v; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < K; k++) {                       // same slice under the high-mapping-quality prior
+                const int x = x0 + k;
+                vA[x] = baseA[k] + ((x == 0) ? hqOff0 : (x == RO ? -100.0 : hqOn0));
+                vI[x] = baseI[k] + ((x == 0) ? hqOff1 : (x == RO ? -100.0 : hqOn1));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int s = 0; s < 2 * numS; s++) {
+                const int x = s < numS ? s : s - numS;
+                const double v = s < numS ? vA[x] : vI[x];
+                if (v > llHMQ + DD_EPS) { llHMQ = v; mapHMQ = s; }
+            }
+        }
+        const int xR = mapRMQ % numS, xH = mapHMQ % numS;
+        const bool offHap = (xR == 0 || xR == RO);
+        const bool offHapHMQ = (xH == 0 || xH == RO);
+
+        // ================= traceback: computeMAPState (:1148-1165), every lane redundantly =================
+        {
+            int s = mapHMQ;
+            if (lane == 0) ms[bMid] = (int16_t)s;
+            for (int b = bMid; b > 0; b--) {                 // mapState[b-1] = btf[b][mapState[b]]
+                const bool ins = s >= numS;
+                const int x = ins ? s - numS : s;
+                const unsigned byte = bt[(size_t)b * NP + x];
+                const unsigned ch = byte & 15u;
+                int p;
+                if (ins) p = (byte & 16u) ? x : s;
+                else if (x == 0) p = 0;
+                else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
+                else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
+                s = p;
+                if (lane == 0) ms[b - 1] = (int16_t)s;
+            }
+            s = mapHMQ;
+            for (int b = bMid; b < L - 1; b++) {             // mapState[b+1] = btb[b][mapState[b]] (row b+1)
+                const bool ins = s >= numS;
+                const int x = ins ? s - numS : s;
+                const unsigned byte = bt[(size_t)(b + 1) * NP + x];
+                const unsigned ch = byte & 15u;
+                int p;
+                if (ins) p = (byte & 16u) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : s;
+                else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
+                else if (x == RO) p = (ch == 0) ? RO : numS + RO;
+                else p = (ch == 0) ? numS + x : x + (int)ch;
+                s = p;
+                if (lane == 0) ms[b + 1] = (int16_t)s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ================= reportVariants (:1351-1475): hpos + QC counters, lane-parallel over read bases ====
+        int nIndel = 0, nMis = 0, nBQT = 0, nmmBQT = 0, nMML = 0, nMMR = 0;
+        int firstB = 0x7fffffff, lastB = -1;
+        const double thr = T[TC_BQT];
+        int16_t *hp_out = P.out.hpos ? P.out.hpos + hpos_base + (so - rs_base) : nullptr;
+        for (int b0 = 0; b0 < L; b0 += 64) {
+            const int b = b0 + lane;
+            double cb = 0.0;
+            if (b < L) {
+                const int s = ms[b];
+                const bool ins = s >= numS;
+                const int x = ins ? s - numS : s;
+                int hp;
+                if (x == 0) hp = DD_HPOS_LO;
+                else if (x == RO) hp = DD_HPOS_RO;
+                else if (ins) {
+                    hp = DD_HPOS_INS;
+                    if (b == 0 || ms[b - 1] < numS) nIndel++;                     // start of an insertion run
+                } else {
+                    hp = x - 1;
+                    firstB = hp < firstB ? hp : firstB;
+                    lastB = hp > lastB ? hp : lastB;
+                    const int qi = rdQ[b];
+                    const double q = T[T_QUAL + 4 * qi + 3];
+                    const bool hiq = q > thr;
+                    if (hiq) { nBQT++; cb = T[T_QUAL + 4 * qi + 2]; }
+                    const int rc = rdC[b];
+                    if (rc != (int)sc[x]) {                                        // read.seq[b]!=hap.seq[s-1]
+                        if (hiq) nmmBQT++;
+                        if (b < 6) nMML++;
+                        if (b > L - 6) nMMR++;
+                        if (q > 0.95) nMis++;
+                    }
+                    if (b < L - 1) {
+                        const int ns = ms[b + 1];
+                        if (ns < numS && ns - s > 1) nIndel++;                     // deletion (:1437-1453)
+                    }
+                }
+                if (hp_out) hp_out[b] = (int16_t)hp;
+            }
+            // contrib must not alias anything still needed: bt is dead after the traceback
+            if (b < L) contrib[b] = cb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // integer reductions across the wave
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            nIndel += __shfl_xor(nIndel, off);
+            nMis += __shfl_xor(nMis, off);
+            nBQT += __shfl_xor(nBQT, off);
+            nmmBQT += __shfl_xor(nmmBQT, off);
+            nMML += __shfl_xor(nMML, off);
+            nMMR += __shfl_xor(nMMR, off);
+            const int f = __shfl_xor(firstB, off), l2 = __shfl_xor(lastB, off);
+            firstB = f < firstB ? f : firstB;
+            lastB = l2 > lastB ? l2 : lastB;
+        }
+        if (firstB == 0x7fffffff) firstB = -1;
+        // mLogBQ: the reference adds log10(1-q) base by base in read order (:1404-1407); fp64 + is not
+        // associative, so sum serially (adding +0.0 for skipped bases is exact).
+        double mLogBQ = 0.0;
+        for (int b = 0; b < L; b++) mLogBQ += contrib[b];
+
+        // hapIndelCovered / hapSNPCovered (:1465-1472; AlignedVariant::isCovered Variant.hpp:125-128)
+        if (P.out.var_covered && nv > 0) {
+            const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
+            for (int i = lane; i < nv; i += 64) {
+                const int sR = P.hap_var[2 * (P.hap_var_off[g] + i)];
+                const int eR = P.hap_var[2 * (P.hap_var_off[g] + i) + 1];
+                P.out.var_covered[vb + i] = (firstB + P.padCover <= sR && lastB - P.padCover >= eR) ? 1 : 0;
+            }
+        }
+
+        if (lane == 0) {
+            int status = DD_PAIR_OK;
+            if (ll > 0.1) status = DD_PAIR_LLPOS;                         // DInDel.cpp:1722
+            else if (ll != ll || ll == NEG_INF || ll == -NEG_INF) status = DD_PAIR_NAN;   // DInDel.cpp:1732
+            P.out.ll[pair] = ll;
+            P.out.status[pair] = status;
+            if (P.out.llOn) P.out.llOn[pair] = llOn;
+            if (P.out.llOff) P.out.llOff[pair] = llOff;
+            if (P.out.mLogBQ) P.out.mLogBQ[pair] = mLogBQ;
+            if (P.out.offHap) P.out.offHap[pair] = offHap ? 1 : 0;
+            if (P.out.offHapHMQ) P.out.offHapHMQ[pair] = offHapHMQ ? 1 : 0;
+            if (P.out.numIndels) P.out.numIndels[pair] = (int16_t)nIndel;
+            if (P.out.numMismatch) P.out.numMismatch[pair] = (int16_t)nMis;
+            if (P.out.nBQT) P.out.nBQT[pair] = (int16_t)nBQT;
+            if (P.out.nmmBQT) P.out.nmmBQT[pair] = (int16_t)nmmBQT;
+            if (P.out.nMMLeft) P.out.nMMLeft[pair] = (int16_t)nMML;
+            if (P.out.nMMRight) P.out.nMMRight[pair] = (int16_t)nMMR;
+            if (P.out.firstBase) P.out.firstBase[pair] = (int16_t)firstB;
+            if (P.out.lastBase) P.out.lastBase[pair] = (int16_t)lastB;
+        }
+        // the next read reuses rdE/rdC/ms/bt of this wave: all of this pair's LDS reads precede (in program
+        // order, same wave) the next pair's LDS writes, and DS ops of one wave execute in order.
+    }
+}
+
+// onHap[r] = 1 iff any haplotype of the window has !offHapHMQ for read r (DInDel.cpp:1710, 1720)
+__global__ void dd_onhap_kernel(const KernelArgs P)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.n_reads) return;
+    // window of read r: binary search in win_read_off
+    int lo = 0, hi = P.n_windows;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (P.win_read_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int w = lo;
+    const int H = P.win_hap_off[w + 1] - P.win_hap_off[w];
+    const int r0 = P.win_read_off[w];
+    const int R = P.win_read_off[w + 1] - r0;
+    const int64_t base = P.win_pair_off[w] + (r - r0);
+    int on = 0;
+    for (int h = 0; h < H; h++) {
+        const int64_t p = base + (int64_t)h * R;
+        if (P.out.status[p] != DD_PAIR_HAPSIZE && !P.out.offHapHMQ[p]) on = 1;
+    }
+    P.out.onHap[r] = (uint8_t)on;
+}
+
+template <int K, int D>
+static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((dd_hmm_kernel<K, D>), grid, dim3(waves * 64), lds, st, A);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
+{
+    switch (K) {
+    case 1: return launch_one<1, D>(A, grid, waves, lds, st);
+    case 2: return launch_one<2, D>(A, grid, waves, lds, st);
+    case 3: return launch_one<3, D>(A, grid, waves, lds, st);
+    case 4: return launch_one<4, D>(A, grid, waves, lds, st);
+    case 6: return launch_one<6, D>(A, grid, waves, lds, st);
+    case 8: return launch_one<8, D>(A, grid, waves, lds, st);
+    case 12: return launch_one<12, D>(A, grid, waves, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+{
+    dim3 g(grid);
+    switch (Dt) {
+    case 6: return launch_k<6>(K, A, g, waves, lds, st);
+    case 11: return launch_k<11>(K, A, g, waves, lds, st);
+    case 12: return launch_k<12>(K, A, g, waves, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)
+{
+    if (A.n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dd_onhap_kernel, dim3((A.n_reads + 255) / 256), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
+} // namespace ddk

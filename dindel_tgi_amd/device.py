@@ -1,0 +1,85 @@
+"""Device-resident batches: torch owns HBM and the stream, the C ABI (dd_launch_device) does the work.
+
+PyTorch is plumbing here (allocation, streams, torch.distributed); no torch op touches the data path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .batch import PackedBatch, RESULT_DTYPES, result_lengths
+
+_TORCH_DT = {np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8, np.dtype(np.int16): torch.int16,
+             np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+
+
+def _to_dev(arr, device):
+    a = np.ascontiguousarray(arr)
+    if a.dtype == np.uint32:                      # torch has no uint32 arithmetic; ship the bits as int32
+        a = a.view(np.int32)
+    if a.size == 0:
+        a = np.zeros(1, a.dtype)
+    return torch.from_numpy(a).to(device, non_blocking=False)
+
+
+class DeviceBatch:
+    """A PackedBatch resident in HBM + the dd_device_batch that points at it."""
+
+    def __init__(self, pb: PackedBatch, params: capi.dd_params, device="cuda:0"):
+        lib = capi.load()
+        self.pb, self.params, self.device = pb, params, torch.device(device)
+        a = pb.a
+        t = {}
+        for k in ["win_hap_off", "win_read_off", "win_hap_start", "hap_seq_off", "hap_seq", "hap_var_off", "hap_var",
+                  "read_seq_off", "read_seq", "read_qidx", "read_mqidx", "read_start", "read_flags"]:
+            t[k] = _to_dev(a[k], self.device)
+        hb = pb.ctypes_batch()
+        hap_window = np.zeros(max(pb.n_haps, 1), np.int32)
+        po = np.zeros(pb.n_windows + 1, np.int64); ho = np.zeros_like(po); vo = np.zeros_like(po)
+        rc = lib.dd_build_index(C.byref(hb), hap_window.ctypes.data_as(capi.c_i32p), po.ctypes.data_as(capi.c_i64p),
+                                ho.ctypes.data_as(capi.c_i64p), vo.ctypes.data_as(capi.c_i64p))
+        if rc != 0:
+            raise RuntimeError("dd_build_index: " + capi.last_error())
+        tables = np.zeros(capi.DD_TABLE_DOUBLES, np.float64)
+        rc = lib.dd_build_tables(C.byref(params), hb.qual_table, hb.n_qual, hb.mapq_table, hb.n_mapq,
+                                 tables.ctypes.data_as(capi.c_f64p))
+        if rc < 0:
+            raise RuntimeError("dd_build_tables: " + capi.last_error())
+        t["hap_window"] = _to_dev(hap_window, self.device)
+        t["win_pair_off"] = _to_dev(po, self.device)
+        t["win_hpos_off"] = _to_dev(ho, self.device)
+        t["win_varcov_off"] = _to_dev(vo, self.device)
+        t["tables"] = _to_dev(tables, self.device)
+        self.t = t
+        db = capi.dd_device_batch()
+        db.n_windows, db.n_haps, db.n_reads = pb.n_windows, pb.n_haps, pb.n_reads
+        db.max_hap_len, db.max_read_len = pb.max_hap_len, pb.max_read_len
+        for k, v in t.items():
+            setattr(db, k, v.data_ptr())
+        db.n_qual, db.n_mapq = hb.n_qual, hb.n_mapq
+        self.db = db
+        # results
+        n = result_lengths(pb)
+        self.out = {k: torch.zeros(max(n[k], 1), dtype=_TORCH_DT[np.dtype(RESULT_DTYPES[k])], device=self.device)
+                    for k, _ in capi.RESULT_FIELDS}
+        dr = capi.dd_device_result()
+        for k, _ in capi.RESULT_FIELDS:
+            setattr(dr, k, self.out[k].data_ptr())
+        self.dr = dr
+        self._n = n
+
+    def launch(self, stream=None):
+        """Enqueue the path on `stream` (default: torch's current stream on this device). Asynchronous."""
+        lib = capi.load()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        rc = lib.dd_launch_device(C.byref(self.params), C.byref(self.db), C.byref(self.dr), None, 0,
+                                  C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dd_launch_device rc=%d: %s" % (rc, capi.last_error()))
+
+    def results(self):
+        """Host copies (numpy) of the outputs, trimmed to their logical lengths."""
+        torch.cuda.synchronize(self.device)
+        return {k: self.out[k][:self._n[k]].cpu().numpy() for k, _ in capi.RESULT_FIELDS}

@@ -1,0 +1,196 @@
+/*
+ * dindel_hmm.h — C ABI of the MI355X-native read x candidate-haplotype HMM likelihood path.
+ *
+ * This is the drop-in boundary for ONE hot path of genome/dindel-tgi:
+ *
+ *     void DetInDel::computeLikelihoods(const vector<Haplotype>& haps, const vector<Read>& reads,
+ *                                       vector<vector<MLAlignment> >& liks,
+ *                                       uint32_t leftPos, uint32_t rightPos, vector<int>& onHap);
+ *                                                  (reference: DInDel.hpp:136, DInDel.cpp:1707-1739)
+ *
+ * which, per (haplotype, read) pair, constructs an ObservationModelFBMaxErr and calls
+ * calcLikelihood() (reference: ObservationModelFB.cpp:1631-1829, 1057-1165, 1351-1475).
+ * Everything is plain pointers and sizes; no STL, no torch types.  One call processes a BATCH of
+ * windows (the reference processes one window per call; a GPU needs many to fill 256 CUs).
+ *
+ * Two ways in:
+ *   (1) dd_compute_likelihoods()  — host pointers in, host pointers out.  The library owns device
+ *       memory, H2D/D2H and the launch.  This is what the reference's C++ host would bind.
+ *   (2) dd_workspace_bytes() / dd_build_tables() / dd_launch_device() — every buffer is a DEVICE
+ *       pointer owned by the caller (e.g. torch tensors), launch on a caller-supplied hipStream_t.
+ *       bench.py and the multi-GPU driver use this so inputs are resident in HBM when timing starts.
+ *
+ * There is NO CPU fallback behind this ABI: without a HIP device every compute entry point returns
+ * DD_ERR_NO_DEVICE.  The CPU restatement lives in oracle/ and is test infrastructure only.
+ */
+#ifndef DINDEL_HMM_H
+#define DINDEL_HMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+/* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
+#define DD_HPOS_INS (-1)
+#define DD_HPOS_DEL (-2)
+#define DD_HPOS_LO  (-3)
+#define DD_HPOS_RO  (-4)
+
+/* return codes of the entry points */
+#define DD_SUCCESS            0
+#define DD_ERR_NO_DEVICE     -1   /* no HIP device / HIP runtime error; message via dd_last_error() */
+#define DD_ERR_INVALID       -2   /* malformed batch (offsets not monotone, null pointer, ...)       */
+#define DD_ERR_UNSUPPORTED   -3   /* shape or option outside what the kernels cover (see limits)     */
+#define DD_ERR_HIP           -4
+
+/* per-pair status, mapped by the host adapter to the reference's throw strings / exit:
+ *   1 -> throw string("hapSize error.")   ObservationModelFB.cpp:47
+ *   2 -> throw string("Nan detected")     DInDel.cpp:1732-1735
+ *   3 -> "Likelihood>0", exit(1)          DInDel.cpp:1722-1731                                   */
+#define DD_PAIR_OK            0
+#define DD_PAIR_HAPSIZE       1
+#define DD_PAIR_NAN           2
+#define DD_PAIR_LLPOS         3
+
+/* kernel limits (checked on the host before launch) */
+#define DD_MAX_HAP_LEN      766   /* numS = Hs+2 <= 64 lanes x 12 positions                         */
+#define DD_MAX_READ_LEN    1024
+#define DD_MAX_LENGTH_DEL    11   /* D = maxLengthDel+1 <= 12: choice fits 4 bits, 5*D match bits fit 64 */
+#define DD_MAX_QUAL_TABLE   256
+#define DD_HP_TABLE          64   /* homopolymer run lengths >= 52 are all capped at 0.99            */
+
+/* Mirrors the fields of ObservationModelParameters the path reads — ObservationModel.hpp:28-99. */
+typedef struct dd_params {
+    double  pError;                  /* probability of a read indel                                  */
+    double  pMut;                    /* probability of a mutation in the read                        */
+    double  pFirstgLO;               /* P(first on-haplotype base | left of haplotype) = 0.01        */
+    double  mapQualThreshold;        /* phred cap on the read mapping quality ("capMapQualThreshold") */
+    double  checkBaseQualThreshold;  /* 0.95: base-quality threshold for nBQT / nmmBQT / mLogBQ      */
+    int32_t maxLengthDel;            /* = maxLengthIndel; numT = maxLengthDel+2                      */
+    int32_t padCover;                /* "flankRefSeq"                                                */
+    int32_t bMid;                    /* -1 = compute from overlap (ObservationModelFB.cpp:96)        */
+    int32_t forceReadOnHaplotype;    /* ObservationModelFB.cpp:307-316                               */
+    int32_t mapUnmappedReads;        /* must be 0 (needs Library insert-size pmf; out of scope)      */
+} dd_params;
+
+/* ObservationModelParameters::setDefaultValues() — ObservationModel.hpp:39-64 */
+void dd_params_struct_defaults(dd_params *p);
+/* the set main() installs from the CLI defaults — DInDel.cpp:3937-3949, 4122-4157 */
+void dd_params_cli_defaults(dd_params *p);
+
+/*
+ * One batch = n_windows windows, CSR-packed.  Window w owns haplotypes [win_hap_off[w], win_hap_off[w+1])
+ * and reads [win_read_off[w], win_read_off[w+1]).  Pairs are produced hap-major then read, like
+ * liks[hidx][r]:   pair(w,h,r) = win_pair_off[w] + h * R_w + r .
+ *
+ * Base qualities and mapping qualities are passed as one-byte indices into small tables of the
+ * probabilities the reference stores in Read::qual / Read::mapQual (Read.hpp:127-148): BAM gives
+ * integer phred, so at most 94 / 256 distinct values occur; the host adapter dedups arbitrary
+ * doubles.  The logs of those probabilities are taken ON THE HOST with libm (dd_build_tables) so
+ * that the device does only add / compare / select and cannot differ from glibc's log().
+ */
+typedef struct dd_batch {
+    int32_t        n_windows;
+    const int32_t *win_hap_off;    /* [n_windows+1]                                                 */
+    const int32_t *win_read_off;   /* [n_windows+1]                                                 */
+    const uint32_t*win_hap_start;  /* [n_windows]   leftPos = hapStart of every model in the window  */
+
+    const int32_t *hap_seq_off;    /* [n_haps+1]    into hap_seq                                    */
+    const char    *hap_seq;        /* haplotype bases, any byte; 'N' matches everything              */
+    const int32_t *hap_var_off;    /* [n_haps+1]    into hap_var (units: variants); may be NULL      */
+    const int32_t *hap_var;        /* per variant of the HAPLOTYPE: {startRead, endRead}
+                                      (AlignedVariant, Variant.hpp:125-128): hap.indels in map order
+                                      then hap.snps in map order — ObservationModelFB.cpp:1465-1472  */
+
+    const int32_t *read_seq_off;   /* [n_reads+1]   into read_seq / read_qidx                       */
+    const char    *read_seq;       /* read bases                                                     */
+    const uint8_t *read_qidx;      /* per base: index into qual_table                                */
+    const uint8_t *read_mqidx;     /* [n_reads]     index into mapq_table                            */
+    const uint32_t*read_start;     /* [n_reads]     uint32_t(read.posStat.first)                     */
+    const uint8_t *read_flags;     /* [n_reads]     bit0 = read.isUnmapped() (BAM flag 0x4)          */
+
+    int32_t        n_qual;  const double *qual_table;  /* P(base correct), Read.hpp:143-148          */
+    int32_t        n_mapq;  const double *mapq_table;  /* read.mapQual,    Read.hpp:127-131          */
+} dd_batch;
+
+/* Per (window,hap,read) pair, in pair order.  Any output pointer may be NULL (then not written),
+ * except ll and status. Mirrors MLAlignment (MLAlignment.hpp:28-76). */
+typedef struct dd_result {
+    double  *ll, *llOn, *llOff, *mLogBQ;
+    uint8_t *offHap, *offHapHMQ;
+    int16_t *numIndels, *numMismatch, *nBQT, *nmmBQT, *nMMLeft, *nMMRight, *firstBase, *lastBase;
+    int16_t *hpos;        /* L entries per pair, at  hpos_off(w) + h*SL_w + (read_seq_off[r]-read_seq_off[r0(w)]),
+                             SL_w = total read bases of window w;  >=0 hap index, -1 INS, -3 LO, -4 RO */
+    uint8_t *var_covered; /* per (pair, variant of that hap): hapIndelCovered / hapSNPCovered        */
+    int32_t *status;      /* DD_PAIR_*                                                               */
+    uint8_t *onHap;       /* [n_reads] 1 iff any hap of the window has !offHapHMQ (DInDel.cpp:1720)  */
+} dd_result;
+
+/* sizes derived from a batch (host-side, O(n_windows + n_haps)) */
+typedef struct dd_sizes {
+    int64_t n_haps, n_reads, n_pairs;
+    int64_t hap_bases, read_bases;
+    int64_t hpos_len;        /* total int16 entries of dd_result.hpos                                */
+    int64_t var_cov_len;     /* total bytes of dd_result.var_covered                                 */
+    int64_t cells;           /* sum over pairs of L * Hs  (the metric's "cell")                      */
+    int32_t max_hap_len, max_read_len;
+} dd_sizes;
+
+int dd_batch_sizes(const dd_batch *b, dd_sizes *out);
+
+/* Offsets a consumer needs to index the ragged outputs; arrays sized [n_windows+1]. */
+int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off);
+
+/* ---- (1) host-pointer entry point --------------------------------------------------------- */
+/* device >= 0: HIP device ordinal.  Synchronous.  Replaces the body of computeLikelihoods for a
+ * batch of windows. */
+int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+
+/* ---- (2) device-pointer entry points ------------------------------------------------------ */
+/* Table block built on the host with libm (emission logs per quality, bMid priors per mapping
+ * quality, homopolymer indel-error logs, transition constants).  Returns number of doubles written
+ * (<= DD_TABLE_DOUBLES); `out` is host memory that the caller copies to the device. */
+#define DD_TABLE_DOUBLES (32 + 4*DD_MAX_QUAL_TABLE + 4*DD_MAX_QUAL_TABLE + 2*DD_HP_TABLE + 64)
+int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
+                    const double *mapq_table, int n_mapq, double *out);
+
+/* Host-side derived index arrays the kernels need, sized by the caller:
+ * hap_window[n_haps], win_pair_off[n_windows+1], win_hpos_off[n_windows+1], win_varcov_off[n_windows+1] */
+int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off,
+                   int64_t *win_hpos_off, int64_t *win_varcov_off);
+
+typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_batch */
+    int32_t n_windows, n_haps, n_reads;
+    int32_t max_hap_len, max_read_len;
+    const int32_t *win_hap_off, *win_read_off; const uint32_t *win_hap_start;
+    const int32_t *hap_seq_off; const char *hap_seq; const int32_t *hap_var_off, *hap_var;
+    const int32_t *read_seq_off; const char *read_seq; const uint8_t *read_qidx, *read_mqidx;
+    const uint32_t *read_start; const uint8_t *read_flags;
+    const int32_t *hap_window; const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
+    const double  *tables;          /* DD_TABLE_DOUBLES doubles from dd_build_tables               */
+    int32_t n_qual, n_mapq;
+} dd_device_batch;
+
+/* bytes of device scratch dd_launch_device needs for this shape (0 if none) */
+size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b);
+
+/* Enqueue the whole path for the batch on `stream` (a hipStream_t, may be NULL = default stream).
+ * Result pointers are DEVICE pointers.  Asynchronous; no allocation, no synchronisation. */
+int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
+const char *dd_kernel_name(void);
+const char *dd_last_error(void);
+int dd_abi_version(void);
+int dd_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINDEL_HMM_H */

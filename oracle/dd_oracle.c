@@ -1,0 +1,494 @@
+/*
+ * dd_oracle.c — CPU restatement of Dindel's read x haplotype HMM likelihood (ObservationModelFBMaxErr).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under dindel_tgi_amd/ (the product) includes, links or calls
+ * this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
+ * only as the checker / the reported CPU baseline.
+ *
+ * PARITY PIN: the reference cannot be built in this image (Read.hpp:19 needs samtools' bam.h,
+ * Haplotype.hpp:26 / Library.hpp:28 need Boost; both absent, and writing stand-in headers is not
+ * an allowed way to obtain a reference build).  The reference ships no tests or fixtures for this
+ * path.  The oracle is therefore pinned ONLY by the 11 known-answer vectors recorded in
+ * SURVEY.md §8(c) (values the survey captured from the compiled reference: ll to 17 digits, plus
+ * llOff/llOn/hpos/flags where listed), committed as tests/golden/survey_kat.json and checked by
+ * tests/test_oracle_kat.py.  Beyond those vectors parity is UNPINNED: it rests on this file being a
+ * line-by-line restatement of the cited reference code.
+ *
+ * Plain C, fp64, single pair at a time, full alpha/beta/obs/back-pointer arrays exactly like the
+ * reference (ObservationModelFB.cpp:1589-1614) — deliberately NOT structured like the HIP kernel,
+ * so the two are independent derivations of the same specification.
+ *
+ * Every sum is written in the reference's own term order: fp64 addition is not associative and the
+ * argmax uses a 1e-10 hysteresis (updateMax, ObservationModelFB.cpp:877-888).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "dd_oracle.h"
+
+#define EPS 1e-10 /* ObservationModelFB.hpp:25 */
+
+/* ReadIndelErrorModel::getViterbiHPError — ReadIndelErrorModel.hpp:25-50 */
+static double hp_error(int hpLen)
+{
+    static const double hp[10] = { 2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3 };
+    int len = hpLen;
+    double pbe;
+    if (len < 1) len = 1;
+    if (len <= 10) pbe = hp[len - 1];
+    else pbe = hp[9] + 4.3e-4 * (double)(len - 10);
+    pbe *= (double)hpLen;
+    if (pbe > 0.99) pbe = 0.99;
+    return pbe;
+}
+
+/* ObservationModelFBMax::updateMax — ObservationModelFB.cpp:877-888 */
+static inline void update_max(double *destValue, int *destIdx, double newValue, int newIdx)
+{
+    if (newValue > *destValue + EPS) {
+        *destValue = newValue;
+        *destIdx = newIdx;
+    } else if (newValue >= *destValue && newValue <= *destValue + 1e-5 && *destIdx > newIdx) {
+        *destValue = newValue;
+        *destIdx = newIdx;
+    }
+}
+
+typedef struct {
+    int hapSize, numS, readSize, ROState, numT, bMid;
+    double logpLOgLO, logpFirstgLO, logpInsgIns, logpNoInsgIns, logpInsgNoIns, logpNoInsgNoIns;
+    double *logProbError, *logProbNoError; /* [numS] */
+    double *obs, *alpha, *beta;            /* [readSize][2*numS] */
+    int *btf, *btb;                        /* [readSize][2*numS] */
+    int *mapState;                         /* [readSize] */
+} hmm_t;
+
+/* ObservationModelFBMaxErr::passMessageTwoInc — ObservationModelFB.cpp:1715-1773 */
+static void pass_two_inc(const hmm_t *m, double *beta_l, const double *beta_l_1, const double *obs_l_1, int *bt_l)
+{
+    const int hapSize = m->hapSize, numS = m->numS, ROState = m->ROState, numT = m->numT;
+    const double *logProbError = m->logProbError, *logProbNoError = m->logProbNoError;
+    int x, y;
+
+    beta_l[0] = -HUGE_VAL;
+    update_max(&beta_l[0], &bt_l[0], obs_l_1[0] + beta_l_1[0] + m->logpLOgLO + m->logpNoInsgNoIns, 0);
+    update_max(&beta_l[0], &bt_l[0], obs_l_1[1] + beta_l_1[1] + m->logpFirstgLO + m->logpNoInsgNoIns, 1);
+
+    for (x = 1; x <= hapSize; x++) {
+        beta_l[x] = -HUGE_VAL;
+        for (y = 1; y < numT; y++) {
+            int newx = x + y;
+            if (newx > hapSize) newx = ROState;
+            double lpn = logProbNoError[newx];
+            double lpt = logProbError[newx];
+            double lp = (y == 1) ? lpn : (lpt + (double)(y - 1) * m->logpInsgIns);
+            update_max(&beta_l[x], &bt_l[x], lp + lpn + beta_l_1[newx] + obs_l_1[newx], newx);
+        }
+    }
+
+    beta_l[ROState] = -HUGE_VAL;
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[ROState] + beta_l_1[ROState] + logProbNoError[ROState], ROState);
+
+    for (x = 0; x <= hapSize; x++)
+        update_max(&beta_l[x], &bt_l[x], obs_l_1[numS + x] + beta_l_1[numS + x] + logProbError[x + 1], numS + x);
+    x = hapSize + 1;
+    update_max(&beta_l[x], &bt_l[x], obs_l_1[numS + x] + beta_l_1[numS + x], numS + x);
+
+    for (x = 0; x <= hapSize + 1; x++) {
+        beta_l[numS + x] = obs_l_1[numS + x] + beta_l_1[numS + x] + m->logpInsgIns;
+        bt_l[numS + x] = numS + x;
+    }
+
+    update_max(&beta_l[0 + numS], &bt_l[0 + numS], obs_l_1[0] + beta_l_1[0] + m->logpNoInsgIns, 0);
+    for (x = 1; x <= hapSize + 1; x++) {
+        int newx = x + 1;
+        if (newx > ROState) newx = ROState;
+        update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[newx] + beta_l_1[newx] + m->logpNoInsgIns, newx);
+    }
+}
+
+/* ObservationModelFBMaxErr::passMessageTwoDec — ObservationModelFB.cpp:1775-1829 */
+static void pass_two_dec(const hmm_t *m, double *beta_l, const double *beta_l_1, const double *obs_l_1, int *bt_l)
+{
+    const int hapSize = m->hapSize, numS = m->numS, ROState = m->ROState, numT = m->numT;
+    const double *logProbError = m->logProbError, *logProbNoError = m->logProbNoError;
+    int x, y;
+
+    beta_l[ROState] = -HUGE_VAL;
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[ROState] + beta_l_1[ROState] + m->logpLOgLO + m->logpNoInsgNoIns, ROState);
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[hapSize] + beta_l_1[hapSize] + m->logpFirstgLO + m->logpNoInsgNoIns, hapSize);
+
+    for (x = 1; x <= hapSize; x++) {
+        beta_l[x] = -HUGE_VAL;
+        double lpt = logProbError[x];
+        double lpn = logProbNoError[x];
+        for (y = 1; y < numT; y++) {
+            int newx = x - y;
+            if (newx < 0) newx = 0;
+            double lp = (y == 1) ? lpn : (lpt + (double)(y - 1) * m->logpInsgIns);
+            update_max(&beta_l[x], &bt_l[x], obs_l_1[newx] + lp + beta_l_1[newx] + lpn, newx);
+        }
+    }
+    beta_l[0] = obs_l_1[0] + beta_l_1[0] + m->logpNoInsgNoIns;
+    bt_l[0] = 0;
+
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[numS + ROState] + beta_l_1[numS + ROState] + m->logpLOgLO + logProbError[ROState], numS + ROState);
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[numS + hapSize] + beta_l_1[numS + hapSize] + m->logpFirstgLO + logProbError[hapSize], numS + hapSize);
+
+    for (x = 1; x <= hapSize; x++) {
+        int newx = x - 1;
+        if (newx < 0) newx = 0;
+        update_max(&beta_l[x], &bt_l[x], obs_l_1[numS + newx] + beta_l_1[numS + newx] + logProbError[x], numS + newx);
+    }
+
+    for (x = 0; x <= hapSize + 1; x++) {
+        beta_l[numS + x] = obs_l_1[numS + x] + beta_l_1[numS + x] + m->logpInsgIns;
+        bt_l[numS + x] = numS + x;
+    }
+
+    for (x = 1; x <= hapSize + 1; x++)
+        update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[x] + beta_l_1[x] + m->logpNoInsgIns, x);
+}
+
+/* ObservationModelFB::computeBMidPrior — ObservationModelFB.cpp:268-305 (pinsert == 0: mapUnmappedReads off) */
+static void bmid_prior(const hmm_t *m, const dd_params *P, double *prior, double mapQual)
+{
+    double mq = 1.0 - mapQual;
+    int x;
+    size_t i;
+    if (-10.0 * log10(mq) > P->mapQualThreshold) mq = pow(10.0, -P->mapQualThreshold / 10.0);
+    double pOffFirst = mq;
+    const double pinsert = 0.0;
+    for (i = 0; i < 2; i++) {
+        double logpIns = (i == 1) ? (m->logpInsgNoIns) : log(1.0 - exp(m->logpInsgNoIns));
+        prior[i * m->numS + 0] = log(pOffFirst) + logpIns + pinsert;
+        prior[i * m->numS + m->ROState] = -100.0;
+        for (x = 1; x < m->hapSize + 1; x++) prior[i * m->numS + x] = pinsert + log((1.0 - pOffFirst)) + logpIns;
+    }
+}
+
+int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+             double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+             const dd_params *P, ddo_out *out, int *hpos)
+{
+    hmm_t M;
+    hmm_t *m = &M;
+    int b, x, y;
+    memset(out, 0, sizeof(*out));
+    out->firstBase = -1;
+    out->lastBase = -1;
+
+    /* ---- ObservationModelFB::Init — ObservationModelFB.cpp:35-102 ---- */
+    if (P->maxLengthDel > Hs) { out->status = DD_PAIR_HAPSIZE; return DD_PAIR_HAPSIZE; }
+    if (L < 1) { out->status = DD_PAIR_NAN; return DD_PAIR_NAN; } /* reference indexes beta[readSize-1]: undefined */
+    {
+        uint32_t hapEnd = hapStart + (uint32_t)Hs;
+        uint32_t mReadStart = readStartU32;
+        uint32_t readEnd = mReadStart + (uint32_t)L - 1;
+        uint32_t olStart, olEnd;
+        int mid;
+        if (unmapped) {
+            m->bMid = (int)(L / 2);
+        } else {
+            if (mReadStart > hapEnd) m->bMid = (int)(L / 2);
+            else if (readEnd < hapStart) m->bMid = (int)(L / 2);
+            else {
+                olStart = (hapStart > mReadStart) ? hapStart : mReadStart;
+                olEnd = (hapEnd > readEnd) ? readEnd : hapEnd;
+                mid = ((int)olEnd - (int)olStart) / 2 + (int)olStart;
+                m->bMid = mid - (int)mReadStart;
+            }
+        }
+        if (P->bMid != -1) m->bMid = P->bMid;
+        if (m->bMid < 0) m->bMid = 0;
+        if (m->bMid >= L) m->bMid = L - 1;
+    }
+    out->bMid = m->bMid;
+
+    /* ---- initHMM / allocateMemory — :324-349, :1589-1614 ---- */
+    m->hapSize = Hs;
+    m->numS = Hs + 2;
+    m->readSize = L;
+    m->ROState = Hs + 1;
+    const int numS = m->numS, T = 2 * numS, ROState = m->ROState;
+    m->obs = (double *)malloc(sizeof(double) * (size_t)L * T);
+    m->alpha = (double *)malloc(sizeof(double) * (size_t)L * T);
+    m->beta = (double *)malloc(sizeof(double) * (size_t)L * T);
+    m->btf = (int *)calloc((size_t)L * T, sizeof(int));
+    m->btb = (int *)calloc((size_t)L * T, sizeof(int));
+    m->mapState = (int *)calloc((size_t)L, sizeof(int));
+    m->logProbError = (double *)malloc(sizeof(double) * numS);
+    m->logProbNoError = (double *)malloc(sizeof(double) * numS);
+    for (x = 0; x < T; x++) {
+        m->alpha[0 * T + x] = 0.0;
+        m->beta[(size_t)(L - 1) * T + x] = 0.0;
+    }
+
+    /* ---- ObservationModelFBMaxErr::setupTransitionProbs — :1641-1713 ---- */
+    m->logpLOgLO = log(1.0 - P->pFirstgLO);
+    m->logpFirstgLO = log(P->pFirstgLO);
+    m->numT = P->maxLengthDel + 2;
+    m->logpInsgIns = -.5;
+    m->logpNoInsgIns = log(1.0 - exp(m->logpInsgIns));
+    m->logpInsgNoIns = log(P->pError);
+    m->logpNoInsgNoIns = log(1 - P->pError);
+    for (x = 0; x < numS; x++) {
+        m->logProbError[x] = log(1e-5);
+        m->logProbNoError[x] = log(1 - 1e-5);
+    }
+    {
+        int len = 1;
+        double perr = hp_error(1);
+        m->logProbError[1] = log(perr);
+        m->logProbNoError[1] = log(1.0 - perr);
+        for (b = 1; b < Hs; b++) {
+            if (hap[b] == hap[b - 1]) {
+                len++;
+            } else {
+                perr = hp_error(len);
+                m->logProbError[b] = log(perr);
+                m->logProbNoError[b] = log(1.0 - perr);
+                len = 1;
+            }
+        }
+        perr = hp_error(len);
+        m->logProbError[Hs - 1] = log(perr); /* index hapSize-1, as written at :1702 */
+        m->logProbNoError[Hs - 1] = log(1.0 - perr);
+    }
+
+    /* ---- setupReadObservationPotentials — :220-266 ---- */
+    for (b = 0; b < L; b++) {
+        double rq = qual[b];
+        char nuc = readseq[b];
+        double *obs_b = &m->obs[(size_t)b * T];
+        double *obs_b_ins = &obs_b[numS];
+        double *obs_b_noins = obs_b;
+        double pr = rq * (1.0 - P->pMut);
+        double eq = log(.25 + .75 * pr);
+        double uq = log(.75 + 1e-10 - .75 * pr);
+        obs_b_ins[0] = eq;
+        obs_b_ins[Hs + 1] = eq;
+        obs_b_noins[0] = eq;
+        obs_b_noins[Hs + 1] = eq;
+        for (y = 0; y < Hs; y++) {
+            obs_b_ins[y + 1] = eq;
+            if (hap[y] == 'N' || hap[y] == nuc) obs_b_noins[y + 1] = eq;
+            else obs_b_noins[y + 1] = uq;
+        }
+    }
+    if (P->forceReadOnHaplotype) { /* forceOnHap — :307-316 */
+        for (b = 0; b < L; b++) {
+            double *o = &m->obs[(size_t)b * T];
+            o[0] = -1000.0;
+            o[ROState] = -1000.0;
+            o[numS] = -1000.0;
+            o[ROState + numS] = -1000.0;
+        }
+    }
+
+    /* ---- ObservationModelFBMax::computeForwardMessages — :1569-1581 ---- */
+    for (b = 1; b <= m->bMid; b++)
+        pass_two_dec(m, &m->alpha[(size_t)b * T], &m->alpha[(size_t)(b - 1) * T], &m->obs[(size_t)(b - 1) * T], &m->btf[(size_t)b * T]);
+    for (b = L - 1; b > m->bMid; b--)
+        pass_two_inc(m, &m->beta[(size_t)(b - 1) * T], &m->beta[(size_t)b * T], &m->obs[(size_t)b * T], &m->btb[(size_t)(b - 1) * T]);
+
+    /* ---- ObservationModelFBMax::calcLikelihoodFromLastSlice — :1075-1144 ---- */
+    {
+        const double *alpha_l = &m->alpha[(size_t)m->bMid * T];
+        const double *beta_l = &m->beta[(size_t)m->bMid * T];
+        const double *obs_l = &m->obs[(size_t)m->bMid * T];
+        double logLikelihood = -HUGE_VAL;
+        double likOff0 = -HUGE_VAL, likOff1 = -HUGE_VAL;
+        int mapStateRMQ = 0;
+        double llHMQ = -HUGE_VAL;
+        double *priorRMQ = (double *)calloc((size_t)T, sizeof(double));
+        double *priorHMQ = (double *)calloc((size_t)T, sizeof(double));
+        bmid_prior(m, P, priorRMQ, mapQual);
+        bmid_prior(m, P, priorHMQ, 1.0 - 1e-10);
+        for (x = 0, y = 0; x < T; x++, y++) {
+            double v = alpha_l[y] + obs_l[y] + beta_l[y] + priorRMQ[y];
+            if (v > logLikelihood + EPS) { logLikelihood = v; mapStateRMQ = x; }
+            if ((x % numS) == 0) {
+                if (v > likOff0) likOff0 = v;
+            } else if ((x % numS) != ROState) {
+                if (v > likOff1) likOff1 = v;
+            }
+            v = alpha_l[y] + obs_l[y] + beta_l[y] + priorHMQ[y];
+            if (v > llHMQ + EPS) { llHMQ = v; m->mapState[m->bMid] = x; }
+        }
+        out->ll = logLikelihood;
+        out->offHapHMQ = ((m->mapState[m->bMid] % numS) == 0 || (m->mapState[m->bMid] % numS) == ROState) ? 1 : 0;
+        out->offHap = ((mapStateRMQ % numS) == 0 || (mapStateRMQ % numS) == ROState) ? 1 : 0;
+        out->llOff = likOff0;
+        out->llOn = likOff1;
+        free(priorRMQ);
+        free(priorHMQ);
+    }
+
+    /* ---- computeMAPState — :1148-1165 ---- */
+    for (b = m->bMid; b > 0; b--) m->mapState[b - 1] = m->btf[(size_t)b * T + m->mapState[b]];
+    for (b = m->bMid; b < L - 1; b++) m->mapState[b + 1] = m->btb[(size_t)b * T + m->mapState[b]];
+
+    /* ---- reportVariants — :1351-1475 (hpos + counters; variant strings are rebuilt by the host adapter) ---- */
+    out->n_indel = 0;
+    out->n_snp = 0;
+    b = 0;
+    while (b < L) {
+        int s = m->mapState[b];
+        if ((s % numS) > 0 && (s % numS) <= Hs) {
+            if (s >= numS) { /* insertion */
+                int pos = (s % numS) - 1 + 1;
+                int len = 0;
+                int rpos = b;
+                while (b < L && m->mapState[b] >= numS) {
+                    hpos[b] = DD_HPOS_INS;
+                    b++;
+                    len++;
+                }
+                if (out->n_indel < DDO_MAX_VAR) {
+                    out->indel_pos[out->n_indel] = pos;
+                    out->indel_len[out->n_indel] = len;
+                    out->indel_rpos[out->n_indel] = rpos;
+                    out->n_indel++;
+                }
+                out->numIndels++;
+                b--;
+            } else {
+                hpos[b] = s - 1;
+                if (out->firstBase == -1) out->firstBase = s - 1; else if (s - 1 < out->firstBase) out->firstBase = s - 1;
+                if (out->lastBase == -1) out->lastBase = s - 1; else if (s - 1 > out->lastBase) out->lastBase = s - 1;
+                if (qual[b] > P->checkBaseQualThreshold) {
+                    out->nBQT++;
+                    out->mLogBQ += log10(1.0 - qual[b]);
+                }
+                if (readseq[b] != hap[s - 1]) {
+                    if (qual[b] > P->checkBaseQualThreshold) out->nmmBQT++;
+                    if (b < 6) out->nMMLeft++;
+                    if (b > L - 6) out->nMMRight++;
+                    if (qual[b] > 0.95) out->numMismatch++;
+                    if (out->n_snp < DDO_MAX_VAR) {
+                        out->snp_pos[out->n_snp] = s - 1;
+                        out->snp_rpos[out->n_snp] = b;
+                        out->n_snp++;
+                    }
+                }
+                if (b < L - 1) {
+                    int ns = m->mapState[b + 1];
+                    if (ns < numS && ns - s > 1) {
+                        int pos = s + 1 - 1;
+                        int len = -(ns - s - 1);
+                        if (out->n_indel < DDO_MAX_VAR) {
+                            out->indel_pos[out->n_indel] = pos;
+                            out->indel_len[out->n_indel] = len;
+                            out->indel_rpos[out->n_indel] = b;
+                            out->n_indel++;
+                        }
+                        out->numIndels++;
+                    }
+                }
+            }
+        } else {
+            if (s % numS == 0) hpos[b] = DD_HPOS_LO; else hpos[b] = DD_HPOS_RO;
+        }
+        b++;
+    }
+
+    free(m->obs); free(m->alpha); free(m->beta); free(m->btf); free(m->btb); free(m->mapState);
+    free(m->logProbError); free(m->logProbNoError);
+
+    /* ---- DetInDel::computeLikelihoods sanity checks — DInDel.cpp:1722-1735 ---- */
+    if (out->ll > 0.1) out->status = DD_PAIR_LLPOS;
+    else if (isnan(out->ll) || isinf(out->ll)) out->status = DD_PAIR_NAN;
+    return out->status;
+}
+
+/* Whole batch in the product's flat layout (include/dindel_hmm.h) — used by the GPU parity tests as
+ * the comparator and by bench.py as the "port" CPU baseline.  Serial over pairs unless nthreads>1. */
+int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win)
+{
+    int64_t w;
+    int64_t W = B->n_windows;
+    int64_t *pair_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 1));
+    int64_t *hpos_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 1));
+    int64_t *vc_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 1));
+    pair_off[0] = hpos_off[0] = vc_off[0] = 0;
+    for (w = 0; w < W; w++) {
+        int64_t H = B->win_hap_off[w + 1] - B->win_hap_off[w];
+        int64_t Rn = B->win_read_off[w + 1] - B->win_read_off[w];
+        int64_t SL = B->read_seq_off[B->win_read_off[w + 1]] - B->read_seq_off[B->win_read_off[w]];
+        int64_t nv = 0;
+        if (B->hap_var_off) nv = B->hap_var_off[B->win_hap_off[w + 1]] - B->hap_var_off[B->win_hap_off[w]];
+        pair_off[w + 1] = pair_off[w] + H * Rn;
+        hpos_off[w + 1] = hpos_off[w] + H * SL;
+        vc_off[w + 1] = vc_off[w] + nv * Rn;
+    }
+    if (n_win < 0 || first_window + n_win > W) n_win = W - first_window;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (w = first_window; w < first_window + n_win; w++) {
+        int h0 = B->win_hap_off[w], h1 = B->win_hap_off[w + 1];
+        int r0 = B->win_read_off[w], r1 = B->win_read_off[w + 1];
+        int Rn = r1 - r0;
+        int64_t SL = B->read_seq_off[r1] - B->read_seq_off[r0];
+        int maxL = 0, r, h;
+        for (r = r0; r < r1; r++) {
+            int L = B->read_seq_off[r + 1] - B->read_seq_off[r];
+            if (L > maxL) maxL = L;
+        }
+        double *q = (double *)malloc(sizeof(double) * (size_t)(maxL + 1));
+        int *hp = (int *)malloc(sizeof(int) * (size_t)(maxL + 1));
+        int64_t vcbase = vc_off[w];
+        if (R->onHap) for (r = r0; r < r1; r++) R->onHap[r] = 0;
+        for (h = h0; h < h1; h++) {
+            const char *hs = B->hap_seq + B->hap_seq_off[h];
+            int Hs = B->hap_seq_off[h + 1] - B->hap_seq_off[h];
+            int nv = B->hap_var_off ? (B->hap_var_off[h + 1] - B->hap_var_off[h]) : 0;
+            for (r = r0; r < r1; r++) {
+                int so = B->read_seq_off[r];
+                int L = B->read_seq_off[r + 1] - so;
+                int i;
+                ddo_out o;
+                int64_t p = pair_off[w] + (int64_t)(h - h0) * Rn + (r - r0);
+                for (i = 0; i < L; i++) q[i] = B->qual_table[B->read_qidx[so + i]];
+                ddo_pair(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
+                         B->win_hap_start[w], B->read_flags[r] & 1, P, &o, hp);
+                R->ll[p] = o.ll;
+                R->status[p] = o.status;
+                if (R->llOn) R->llOn[p] = o.llOn;
+                if (R->llOff) R->llOff[p] = o.llOff;
+                if (R->mLogBQ) R->mLogBQ[p] = o.mLogBQ;
+                if (R->offHap) R->offHap[p] = (uint8_t)o.offHap;
+                if (R->offHapHMQ) R->offHapHMQ[p] = (uint8_t)o.offHapHMQ;
+                if (R->numIndels) R->numIndels[p] = (int16_t)o.numIndels;
+                if (R->numMismatch) R->numMismatch[p] = (int16_t)o.numMismatch;
+                if (R->nBQT) R->nBQT[p] = (int16_t)o.nBQT;
+                if (R->nmmBQT) R->nmmBQT[p] = (int16_t)o.nmmBQT;
+                if (R->nMMLeft) R->nMMLeft[p] = (int16_t)o.nMMLeft;
+                if (R->nMMRight) R->nMMRight[p] = (int16_t)o.nMMRight;
+                if (R->firstBase) R->firstBase[p] = (int16_t)o.firstBase;
+                if (R->lastBase) R->lastBase[p] = (int16_t)o.lastBase;
+                if (R->hpos && o.status != DD_PAIR_HAPSIZE) {
+                    int16_t *dst = R->hpos + hpos_off[w] + (int64_t)(h - h0) * SL + (so - B->read_seq_off[r0]);
+                    for (i = 0; i < L; i++) dst[i] = (int16_t)hp[i];
+                }
+                if (R->var_covered && nv > 0) {
+                    /* AlignedVariant::isCovered — Variant.hpp:125-128; ObservationModelFB.cpp:1465-1472 */
+                    int64_t vb = vcbase + (int64_t)(B->hap_var_off[h] - B->hap_var_off[h0]) * Rn + (int64_t)(r - r0) * nv;
+                    for (i = 0; i < nv; i++) {
+                        int sR = B->hap_var[2 * (B->hap_var_off[h] + i)];
+                        int eR = B->hap_var[2 * (B->hap_var_off[h] + i) + 1];
+                        R->var_covered[vb + i] = (o.status != DD_PAIR_HAPSIZE && o.firstBase + P->padCover <= sR && o.lastBase - P->padCover >= eR) ? 1 : 0;
+                    }
+                }
+                if (R->onHap && o.status != DD_PAIR_HAPSIZE && !o.offHapHMQ) R->onHap[r] = 1;
+            }
+        }
+        free(q);
+        free(hp);
+    }
+    free(pair_off); free(hpos_off); free(vc_off);
+    return 0;
+}

@@ -1,0 +1,31 @@
+/* dd_oracle.h — interface of the CPU restatement (TEST INFRASTRUCTURE ONLY; see dd_oracle.c header). */
+#ifndef DD_ORACLE_H
+#define DD_ORACLE_H
+#include "../include/dindel_hmm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDO_MAX_VAR 64
+
+typedef struct ddo_out {
+    double ll, llOn, llOff, mLogBQ;
+    int32_t offHap, offHapHMQ, numIndels, numMismatch, nBQT, nmmBQT, nMMLeft, nMMRight, firstBase, lastBase;
+    int32_t bMid, status;
+    /* variants the read shows relative to the haplotype, in read order (reportVariants :1375-1463) */
+    int32_t n_indel, indel_pos[DDO_MAX_VAR], indel_len[DDO_MAX_VAR] /* >0 ins, <0 del */, indel_rpos[DDO_MAX_VAR];
+    int32_t n_snp, snp_pos[DDO_MAX_VAR], snp_rpos[DDO_MAX_VAR];
+} ddo_out;
+
+/* one (haplotype, read) pair: ObservationModelFBMaxErr(hap, read, hapStart, params).calcLikelihood() */
+int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+             double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+             const dd_params *P, ddo_out *out, int *hpos /* [L] */);
+
+/* a batch in the product's flat layout; windows [first_window, first_window+n_win) (n_win<0: all) */
+int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+"""ctypes wrapper of oracle/libdd_oracle.so — the CPU restatement used ONLY as the checker in tests,
+smoke() and bench.py's cpu_baseline leg (see oracle/dd_oracle.c header)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dindel_tgi_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libdd_oracle.so")
+MAXV = 64
+
+
+class ddo_out(C.Structure):
+    _fields_ = ([("ll", C.c_double), ("llOn", C.c_double), ("llOff", C.c_double), ("mLogBQ", C.c_double)] +
+                [(n, C.c_int32) for n in ("offHap offHapHMQ numIndels numMismatch nBQT nmmBQT nMMLeft nMMRight "
+                                          "firstBase lastBase bMid status").split()] +
+                [("n_indel", C.c_int32), ("indel_pos", C.c_int32 * MAXV), ("indel_len", C.c_int32 * MAXV),
+                 ("indel_rpos", C.c_int32 * MAXV), ("n_snp", C.c_int32), ("snp_pos", C.c_int32 * MAXV),
+                 ("snp_rpos", C.c_int32 * MAXV)])
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "dd_oracle.c")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.ddo_pair.argtypes = [C.c_char_p, C.c_int, C.c_char_p, capi.c_f64p, C.c_int, C.c_double, C.c_uint32,
+                                  C.c_uint32, C.c_int, C.POINTER(capi.dd_params), C.POINTER(ddo_out),
+                                  C.POINTER(C.c_int)]
+        _lib.ddo_batch.argtypes = [C.POINTER(capi.dd_params), C.POINTER(capi.dd_batch), C.POINTER(capi.dd_result),
+                                   C.c_int, C.c_int64, C.c_int64]
+    return _lib
+
+
+def pair(hap, read, qual, mapQual, read_start, hap_start, params, unmapped=False):
+    """One (haplotype, read) pair -> (ddo_out, hpos list)."""
+    lib = load()
+    L = len(read)
+    q = np.ascontiguousarray(np.broadcast_to(np.asarray(qual, dtype=np.float64), (L,)))
+    hp = (C.c_int * max(L, 1))()
+    o = ddo_out()
+    lib.ddo_pair(hap.encode(), len(hap), read.encode(), q.ctypes.data_as(capi.c_f64p), L, float(mapQual),
+                 read_start & 0xFFFFFFFF, hap_start & 0xFFFFFFFF, 1 if unmapped else 0, C.byref(params),
+                 C.byref(o), hp)
+    return o, list(hp)[:L]
+
+
+def batch(params, pb, nthreads=1, first_window=0, n_win=-1):
+    """Whole PackedBatch through the oracle -> dict of numpy result arrays (same layout as the product)."""
+    from dindel_tgi_amd.batch import alloc_result
+    lib = load()
+    arrs, res = alloc_result(pb)
+    b = pb.ctypes_batch()
+    rc = lib.ddo_batch(C.byref(params), C.byref(b), C.byref(res), nthreads, first_window, n_win)
+    assert rc == 0
+    return arrs
