@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — read x haplotype HMM likelihood throughput on MI355X (BASELINE.json metric).
+
+One *step* = one pass of the hot path (dd_launch_device: every (haplotype, read) pair of the batch ->
+log-likelihoods, flags, hpos, QC counters) over one batch of synthetic windows that is already resident
+in HBM.  Workload at N=1 is BASELINE.json configs[1]: 10,000 windows x 8 haplotypes x 200 reads
+(100 bp, Q30), CLI-default model parameters.  With N>1 every rank owns its own contiguous block of
+10,000 windows (weak scaling), and each step ends with the RCCL gather of the per-pair log-likelihoods
+and off-haplotype flags to rank 0 that north_star names.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from dindel_tgi_amd import capi, synth
+from dindel_tgi_amd.device import DeviceBatch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# fp64 VALU ceiling for this recurrence, SURVEY.md §8(d): ~32 fp64 add/cmp/select per cell against
+# 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz = 39.3e12 non-FMA fp64 op/s
+VALU_CELLS_PER_S = 39.3e12 / 32.0
+
+
+def algorithmic_bytes_per_pair(L, Hs, R):
+    """L bases + L quals + 16 (mapQual, start, flags) + Hs/R + 32 (ll, llOn, llOff, packed
+    flags/counters) + 2L (hpos int16) = 4L + 48 + Hs/R."""
+    return 4.0 * L + 48.0 + float(Hs) / R
+
+
+def cpu_baseline(pb, params, seconds_target=15.0):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
+    from tests import _oracle
+    threads = max(1, min(16, os.cpu_count() or 1))
+    n_win = min(pb.n_windows, 2)
+    t0 = time.time()
+    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win)
+    dt = time.time() - t0
+    per_win = dt / n_win
+    n_win = int(max(threads, min(pb.n_windows, seconds_target / max(per_win, 1e-9))))
+    t0 = time.time()
+    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win)
+    dt = time.time() - t0
+    a = pb.a
+    h1, r1 = int(a["win_hap_off"][n_win]), int(a["win_read_off"][n_win])
+    cells = 0
+    hl = np.diff(a["hap_seq_off"]).astype(np.int64)
+    rl = np.diff(a["read_seq_off"]).astype(np.int64)
+    for w in range(n_win):
+        cells += int(hl[a["win_hap_off"][w]:a["win_hap_off"][w + 1]].sum()) * int(rl[a["win_read_off"][w]:a["win_read_off"][w + 1]].sum())
+    return dict(value=cells / dt, unit="cells/s", cores=threads, kind="port",
+                sample="first %d of the %d windows (%d pairs), oracle/dd_oracle.c with %d OpenMP threads, %.1f s"
+                       % (n_win, pb.n_windows, int(pb.win_pair_off[n_win]), threads, dt),
+                windows_per_s=n_win / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--windows", type=int, default=10000, help="windows per GPU")
+    ap.add_argument("--haps", type=int, default=8)
+    ap.add_argument("--reads", type=int, default=200)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--hap-len", type=int, default=120)
+    ap.add_argument("--max-length-del", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the likelihood path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    params = capi.params_cli_defaults()
+    params.maxLengthDel = args.max_length_del
+    # rank r owns windows [r*W, (r+1)*W) of the job; its block is generated from seed+r
+    pb = synth.generate(args.windows, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len,
+                        seed=0x9E3779B9 + rank)
+    dev = DeviceBatch(pb, params, device)
+    n_pairs, cells = pb.n_pairs, pb.cells
+
+    gather_bufs = None
+    if world > 1 and rank == 0:
+        gather_bufs = {k: [torch.empty_like(dev.out[k]) for _ in range(world)] for k in ("ll", "offHap", "offHapHMQ")}
+
+    def step():
+        dev.launch()
+        if world > 1:
+            for k in ("ll", "offHap", "offHapHMQ"):
+                dist.gather(dev.out[k], gather_bufs[k] if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        dev.launch()
+        ev[i][1].record()
+        if world > 1:
+            for k in ("ll", "offHap", "offHapHMQ"):
+                dist.gather(dev.out[k], gather_bufs[k] if rank == 0 else None, dst=0)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+
+    # sanity: every pair finished with status OK and a finite negative log-likelihood
+    res_status = dev.out["status"][:n_pairs]
+    assert int((res_status != 0).sum().item()) == 0, "non-OK pair status in the bench batch"
+    assert bool(torch.isfinite(dev.out["ll"][:n_pairs]).all().item())
+
+    if rank == 0:
+        total_cells = cells * world * args.steps
+        total_windows = args.windows * world * args.steps
+        value = total_cells / elapsed
+        bpp = algorithmic_bytes_per_pair(args.read_len, args.hap_len, args.reads)
+        achieved = bpp * n_pairs / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "read-haplotype HMM cells/s", "value": value, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d windows/GPU x %d haplotypes x %d reads, %d bp reads (Q30), %d bp haplotypes, "
+                                   "maxLengthDel=%d (BASELINE.json configs[1])"
+                                   % (args.windows, args.haps, args.reads, args.read_len, args.hap_len, args.max_length_del),
+                       "windows_per_gpu": args.windows, "pairs_per_gpu": n_pairs, "cells_per_gpu": cells,
+                       "sharding": "contiguous window blocks per rank; gather of ll+flags to rank 0" if world > 1 else "single GPU"},
+            "windows_per_s": total_windows / elapsed,
+            "pairs_per_s": n_pairs * world * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": capi.load().dd_kernel_name().decode(), "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_pair": bpp,
+                         "note": "scalar max-plus fp64 recurrence: bound by fp64 VALU/LDS, not HBM (SURVEY §8d); "
+                                 "valu_fp64 gives the binding ceiling"},
+            "valu_fp64": {"achieved_cells_per_s": cells / (kern_ms * 1e-3), "ceiling_cells_per_s": VALU_CELLS_PER_S,
+                          "frac": cells / (kern_ms * 1e-3) / VALU_CELLS_PER_S},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pb, params)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,6 +110,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the likelihood path)" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Load it
+    # FIRST so that our NEEDED libamdhip64.so.7 binds to the same copy; otherwise device pointers and
+    # streams handed over from torch belong to a different runtime instance.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.dd_params_struct_defaults.argtypes = [C.POINTER(dd_params)]
     lib.dd_params_struct_defaults.restype = None
