@@ -1,0 +1,125 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/dindel_hmm.h declares,
+its host bookkeeping agrees with the numpy packer, and compute entry points refuse to run without a GPU
+(there is no CPU fallback).  No compute calls here."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dindel_tgi_amd import capi, synth
+from dindel_tgi_amd.batch import ReadRec, Window, alloc_result, pack, phred_to_prob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dindel_hmm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dd_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert set(names) == set(capi.EXPORTS), (names, capi.EXPORTS)
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.dd_abi_version() == 1
+    assert lib.dd_kernel_name().decode() == "dd_hmm_kernel"
+
+
+def test_param_defaults_match_reference_sets(lib):
+    p = capi.dd_params()
+    lib.dd_params_cli_defaults(C.byref(p))
+    assert p.as_dict() == capi.params_cli_defaults().as_dict()
+    # DInDel.cpp:4154-4157, :4122: pError 5e-4, pMut 1e-5, maxLengthIndel 5, flankRefSeq 2
+    assert (p.pError, p.pMut, p.maxLengthDel, p.padCover, p.mapQualThreshold) == (5e-4, 1e-5, 5, 2, 100.0)
+    lib.dd_params_struct_defaults(C.byref(p))
+    assert p.as_dict() == capi.params_struct_defaults().as_dict()
+    # ObservationModel.hpp:39-64
+    assert (p.pError, p.pMut, p.maxLengthDel, p.padCover, p.pFirstgLO, p.checkBaseQualThreshold, p.bMid) == \
+        (1e-4, 1e-4, 10, 5, 0.01, 0.95, -1)
+
+
+def test_sizes_and_offsets_agree_with_packer(lib):
+    pb = synth.generate(7, H=3, R=11, L=40, hap_len=50, seed=5, vary_read_len=True, mixed_quals=True)
+    b = pb.ctypes_batch()
+    sz = capi.dd_sizes()
+    assert lib.dd_batch_sizes(C.byref(b), C.byref(sz)) == 0
+    assert (sz.n_haps, sz.n_reads, sz.n_pairs) == (pb.n_haps, pb.n_reads, pb.n_pairs)
+    assert (sz.hpos_len, sz.var_cov_len, sz.cells) == (pb.hpos_len, pb.var_cov_len, pb.cells)
+    assert (sz.max_hap_len, sz.max_read_len) == (pb.max_hap_len, pb.max_read_len)
+    po = np.zeros(pb.n_windows + 1, np.int64); ho = np.zeros_like(po); vo = np.zeros_like(po)
+    hw = np.zeros(pb.n_haps, np.int32)
+    assert lib.dd_build_index(C.byref(b), hw.ctypes.data_as(capi.c_i32p), po.ctypes.data_as(capi.c_i64p),
+                              ho.ctypes.data_as(capi.c_i64p), vo.ctypes.data_as(capi.c_i64p)) == 0
+    assert np.array_equal(po, pb.win_pair_off) and np.array_equal(ho, pb.win_hpos_off)
+    assert np.array_equal(vo, pb.win_varcov_off)
+    assert np.array_equal(hw, np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_hap_off"])))
+
+
+def test_tables_are_the_reference_formulas(lib):
+    """dd_build_tables vs the formulas of ObservationModelFB.cpp:226-234, 268-303, 1643-1703 (python math =
+    the same libm)."""
+    p = capi.params_cli_defaults()
+    quals = phred_to_prob([2, 10, 20, 30, 41])
+    mapqs = phred_to_prob([0, 20, 40, 60, 150])
+    out = np.zeros(capi.DD_TABLE_DOUBLES)
+    n = lib.dd_build_tables(C.byref(p), quals.ctypes.data_as(capi.c_f64p), len(quals),
+                            mapqs.ctypes.data_as(capi.c_f64p), len(mapqs), out.ctypes.data_as(capi.c_f64p))
+    assert 0 < n <= capi.DD_TABLE_DOUBLES
+    assert out[0] == math.log(1.0 - 0.01) and out[1] == math.log(0.01) and out[2] == -0.5
+    assert out[3] == math.log(1.0 - math.exp(-0.5)) and out[4] == math.log(5e-4) and out[5] == math.log(1 - 5e-4)
+    TQ, TM, TH = 32, 32 + 1024, 32 + 2048
+    for i, q in enumerate(quals):
+        pr = q * (1.0 - p.pMut)
+        assert out[TQ + 4 * i] == math.log(.25 + .75 * pr)
+        assert out[TQ + 4 * i + 1] == math.log(.75 + 1e-10 - .75 * pr)
+        assert out[TQ + 4 * i + 2] == math.log10(1.0 - q)
+    lIns = [math.log(1.0 - math.exp(math.log(p.pError))), math.log(p.pError)]
+    for i, mqv in enumerate(mapqs):
+        mq = 1.0 - mqv
+        if -10.0 * math.log10(mq) > p.mapQualThreshold:
+            mq = math.pow(10.0, -p.mapQualThreshold / 10.0)
+        for k in range(2):
+            assert out[TM + 4 * i + k] == math.log(mq) + lIns[k] + 0.0
+            assert out[TM + 4 * i + 2 + k] == 0.0 + math.log(1.0 - mq) + lIns[k]
+    base = [2.9e-5] * 4 + [4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3]
+    for ln in (1, 4, 5, 10, 11, 30, 52, 63):
+        pbe = (base[ln - 1] if ln <= 10 else base[9] + 4.3e-4 * float(ln - 10)) * float(ln)
+        pbe = min(pbe, 0.99)
+        assert out[TH + 2 * ln] == math.log(pbe) and out[TH + 2 * ln + 1] == math.log(1.0 - pbe)
+
+
+def _one_window(hap="ACGTACGTACGT", read="ACGTAC"):
+    return pack([Window(1000, [hap], [ReadRec(read, [0.999] * len(read), 0.9999, 1000)])])
+
+
+def test_no_cpu_fallback_and_validation(lib):
+    import torch
+    p = capi.params_cli_defaults()
+    pb = _one_window()
+    arrs, res = alloc_result(pb)
+    b = pb.ctypes_batch()
+    if not torch.cuda.is_available():
+        assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == capi.DD_ERR_NO_DEVICE
+        assert "no CPU fallback" in capi.last_error()
+    # validation happens before any device work
+    bad = _one_window(hap="ACGTRCGTACGT")
+    bb = bad.ctypes_batch()
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(bb), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    p2 = capi.params_cli_defaults(); p2.mapUnmappedReads = 1
+    assert lib.dd_compute_likelihoods(C.byref(p2), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    p3 = capi.params_cli_defaults(); p3.maxLengthDel = 12
+    assert lib.dd_compute_likelihoods(C.byref(p3), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    res2 = capi.dd_result()
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res2), 0) == capi.DD_ERR_INVALID
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libdindel_hmm.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load()
