@@ -56,13 +56,15 @@ int pick_Dt(int D)
 uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
 
 // LDS carve-up for (K, Dt, Lmax); returns total dynamic LDS bytes per workgroup
-size_t lds_layout(int K, int Dt, int Lmax, int waves, ddk::KernelArgs &A)
+size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, ddk::KernelArgs &A)
 {
     const uint32_t NP = 64u * K;
     uint32_t o = 0;
     o = up16(NP + 16);
     A.lds_off_E = o;  o += up16((NP + 2) * 8);
     A.lds_off_N = o;  o += up16((NP + 2) * 8);
+    A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
+    A.n_qual = n_qual;
     A.lds_shared_bytes = o;
     uint32_t wv = 0;
     A.lds_off_A = wv;   wv += up16((2 * Dt + NP) * 8);
@@ -113,6 +115,11 @@ struct DevBuf {
 };
 
 } // namespace
+
+#ifdef DD_STAMPS
+static unsigned long long *g_dbg = nullptr;
+extern "C" void dd_debug_set_stamp_buffer(void *p) { g_dbg = static_cast<unsigned long long *>(p); }
+#endif
 
 extern "C" {
 
@@ -284,13 +291,16 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
     A.win_varcov_off = b->win_varcov_off; A.tables = b->tables;
     A.out = *r;
+#ifdef DD_STAMPS
+    A.dbg = g_dbg;
+#endif
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
     // 4 waves per workgroup when the back-pointer tiles fit; fewer for long reads x long haplotypes
     int waves = DD_WAVES;
-    size_t lds = lds_layout(K, Dt, b->max_read_len, waves, A);
+    size_t lds = lds_layout(K, Dt, b->max_read_len, b->n_qual, waves, A);
     while (lds > 160u * 1024u && waves > 1) {
         waves >>= 1;
-        lds = lds_layout(K, Dt, b->max_read_len, waves, A);
+        lds = lds_layout(K, Dt, b->max_read_len, b->n_qual, waves, A);
     }
     if (lds > 160u * 1024u)
         return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length needs more than 160 KiB of LDS per wavefront");

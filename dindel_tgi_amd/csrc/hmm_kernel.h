@@ -48,8 +48,10 @@ struct KernelArgs {
     int32_t D, maxLengthDel, padCover, bMid;
     /* launch geometry */
     int32_t n_split;
+    unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */
-    uint32_t lds_off_E, lds_off_N, lds_shared_bytes, lds_wave_bytes;
+    uint32_t lds_off_E, lds_off_N, lds_off_Q, lds_shared_bytes, lds_wave_bytes;
+    int32_t n_qual;
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
 };
 

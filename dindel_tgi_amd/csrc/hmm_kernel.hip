@@ -29,6 +29,21 @@
 namespace ddk {
 
 #define DD_EPS 1e-10
+
+// Diagnostic build only (-DDD_STAMPS): per-phase s_memtime shares, summed into P.dbg[phase].  Never
+// compiled into the product library; the stamps go to a buffer of their own and feed no output.
+#ifdef DD_STAMPS
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                     \
+        if (lane == 0 && P.dbg) atomicAdd(&P.dbg[i], _t - _tprev);                \
+        _tprev = __builtin_amdgcn_s_memtime();                                    \
+    } while (0)
+#define STAMP_INIT unsigned long long _tprev = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_INIT do { } while (0)
+#endif
 #define NEG_INF (-__builtin_huge_val())
 
 __device__ __forceinline__ int base_code(unsigned char ch)
@@ -45,6 +60,56 @@ __device__ __forceinline__ void update_max(double &dest, int &idx, int &code, do
 {
     if (v > dest + DD_EPS) { dest = v; idx = newIdx; code = newCode; }
     else if (v >= dest && v <= dest + 1e-5 && idx > newIdx) { dest = v; idx = newIdx; code = newCode; }
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// arg max over one HMM slice with the reference's scan semantics (ObservationModelFB.cpp:1096-1102,
+// 1110-1114): states visited in index order, a state replaces the incumbent only if it beats it by
+// more than EPS.  If exactly one state lies within 3e-10 of the true maximum M, that scan provably ends
+// on it (every earlier incumbent is <= M-3e-10 < M-EPS, nothing later exceeds M+EPS), so the parallel
+// max is exact.  Otherwise (near-ties, e.g. repeats) the scan is replayed verbatim from LDS.
+template <int K>
+__device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double (&vI)[K], int x0, int numS,
+                                             double *ldsA, double *ldsI, double &best, int &idx)
+{
+    double m = NEG_INF;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        m = vA[k] > m ? vA[k] : m;
+        m = vI[k] > m ? vI[k] : m;
+    }
+    m = wave_max(m);
+    const double thr = m - 3e-10;
+    int cnt = 0, cand = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const unsigned long long ba = __ballot(vA[k] >= thr), bi = __ballot(vI[k] >= thr);
+        cnt += __popcll(ba) + __popcll(bi);
+        if (ba) cand = (__ffsll((long long)ba) - 1) * K + k;
+        if (bi) cand = numS + (__ffsll((long long)bi) - 1) * K + k;
+    }
+    if (cnt == 1) { best = m; idx = cand; return; }
+#pragma unroll
+    for (int k = 0; k < K; k++) { ldsA[x0 + k] = vA[k]; ldsI[x0 + k] = vI[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    best = NEG_INF;
+    idx = 0;
+    for (int s = 0; s < 2 * numS; s++) {
+        const double v = s < numS ? ldsA[s] : ldsI[s - numS];
+        if (v > best + DD_EPS) { best = v; idx = s; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int K, int D>
@@ -88,6 +153,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     unsigned char *sc = smem;                                   // [NP+16] state codes
     double *shE = reinterpret_cast<double *>(smem + P.lds_off_E);  // [NP+2]
     double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+2]
+    double *shQ = reinterpret_cast<double *>(smem + P.lds_off_Q);  // [n_qual][4] eq, uq, log10(1-q), q
     // ---------------- wave-private region ----------------
     unsigned char *wbase = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
     double *bufA = reinterpret_cast<double *>(wbase + P.lds_off_A);       // [D + NP + D]   index s -> bufA[D+s]
@@ -97,7 +163,6 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
     unsigned char *bt = wbase + P.lds_off_bt;                              // [Lmax][NP] back-pointers
-    double *contrib = reinterpret_cast<double *>(wbase + P.lds_off_bt);   // aliases bt after traceback
 
     const bool hap_ok = (P.maxLengthDel <= Hs);     // else "hapSize error." (ObservationModelFB.cpp:47)
 
@@ -112,6 +177,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
         shE[s] = T[TC_EDEF];
         shN[s] = T[TC_NDEF];
     }
+    for (int s = tid; s < 4 * P.n_qual; s += nthr) shQ[s] = T[T_QUAL + s];
     __syncthreads();
     if (tid == 0) { shE[1] = T[T_HP + 2 * 1]; shN[1] = T[T_HP + 2 * 1 + 1]; }
     __syncthreads();
@@ -187,6 +253,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     const int64_t hpos_base = P.win_hpos_off[w] + (int64_t)(g - h0) * SL;
     const int nv = P.hap_var_off ? (P.hap_var_off[g + 1] - P.hap_var_off[g]) : 0;
 
+    STAMP_INIT;
+    STAMP(0);   // per-haplotype setup
     // ======================= loop over this wave's reads =======================
     for (int ri = split * nwav + wave; ri < R; ri += P.n_split * nwav) {
         const int r = r0 + ri;
@@ -226,12 +294,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             const int qi = P.read_qidx[so + b];
             rdC[b] = (unsigned char)base_code((unsigned char)P.read_seq[so + b]);
             rdQ[b] = (unsigned char)qi;
-            rdE[2 * b] = T[T_QUAL + 4 * qi];
-            rdE[2 * b + 1] = T[T_QUAL + 4 * qi + 1];
+            rdE[2 * b] = shQ[4 * qi];
+            rdE[2 * b + 1] = shQ[4 * qi + 1];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        STAMP(1);   // bMid + staging
         double a[K], in[K];           // current slice: "on base x" and "inserted at x"
         // ================= left -> middle: passMessageTwoDec for b = 1..bMid (:1573-1575, :1775-1829)
 #pragma unroll
@@ -315,6 +384,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                 bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];
             }
         }
+        STAMP(2);   // Dec passes
         double al_a[K], al_i[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { al_a[k] = a[k]; al_i[k] = in[k]; }
@@ -405,9 +475,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             }
         }
 
+        STAMP(3);   // Inc passes
         // ================= join at bMid: calcLikelihoodFromLastSlice (:1075-1144) + computeBMidPrior (:268-305)
-        double ll = NEG_INF, llHMQ = NEG_INF, llOff = NEG_INF, llOn = NEG_INF;
-        int mapRMQ = 0, mapHMQ = 0;
+        double ll, llHMQ, llOff, llOn;
+        int mapRMQ, mapHMQ;
         {
             const double eq = rdE[2 * bMid], uq = rdE[2 * bMid + 1];
             const int col = rdC[bMid] > 4 ? 4 : rdC[bMid];
@@ -415,91 +486,88 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             const double prOff0 = T[T_MAPQ + 4 * mqi + 0], prOff1 = T[T_MAPQ + 4 * mqi + 1];
             const double prOn0 = T[T_MAPQ + 4 * mqi + 2], prOn1 = T[T_MAPQ + 4 * mqi + 3];
             const double hqOff0 = T[TC_HMQ + 0], hqOff1 = T[TC_HMQ + 1], hqOn0 = T[TC_HMQ + 2], hqOn1 = T[TC_HMQ + 3];
-            double *vA = bufA + D;                 // [NP] states 0..numS-1   (the row buffers are free now)
-            double *vI = bufI + 1;                 // [NP] inserted states
-            double baseA[K], baseI[K];
+            double vA[K], vI[K], hA[K], hI[K];
+            double on = NEG_INF;
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int x = x0 + k;
                 const double o = ((C.mOwn[k] >> col) & 1u) ? eq : uq;
-                baseA[k] = (al_a[k] + o) + a[k];               // alpha + obs + beta (:1098)
-                baseI[k] = (al_i[k] + eq) + in[k];
-                vA[x] = baseA[k] + ((x == 0) ? prOff0 : (x == RO ? -100.0 : prOn0));
-                vI[x] = baseI[k] + ((x == 0) ? prOff1 : (x == RO ? -100.0 : prOn1));
+                const double baseA = (al_a[k] + o) + a[k];             // alpha + obs + beta (:1098)
+                const double baseI = (al_i[k] + eq) + in[k];
+                vA[k] = baseA + ((x == 0) ? prOff0 : (x == RO ? -100.0 : prOn0));    // read's mapping quality
+                vI[k] = baseI + ((x == 0) ? prOff1 : (x == RO ? -100.0 : prOn1));
+                hA[k] = baseA + ((x == 0) ? hqOff0 : (x == RO ? -100.0 : hqOn0));    // mapQual = 1-1e-10 (:1093)
+                hI[k] = baseI + ((x == 0) ? hqOff1 : (x == RO ? -100.0 : hqOn1));
+                if (x >= 1 && x <= Hs) {                                   // (:1106-1107) plain max
+                    on = vA[k] > on ? vA[k] : on;
+                    on = vI[k] > on ? vI[k] : on;
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // sequential scan in state order, every lane redundantly (wave-uniform): identical to :1096-1117
-            for (int s = 0; s < 2 * numS; s++) {
-                const int x = s < numS ? s : s - numS;
-                const double v = s < numS ? vA[x] : vI[x];
-                if (v > ll + DD_EPS) { ll = v; mapRMQ = s; }
-                if (x == 0) { if (v > llOff) llOff = v; }
-                else if (x != RO) { if (v > llOn) llOn = v; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < K; k++) {                       // same slice under the high-mapping-quality prior
-                const int x = x0 + k;
-                vA[x] = baseA[k] + ((x == 0) ? hqOff0 : (x == RO ? -100.0 : hqOn0));
-                vI[x] = baseI[k] + ((x == 0) ? hqOff1 : (x == RO ? -100.0 : hqOn1));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int s = 0; s < 2 * numS; s++) {
-                const int x = s < numS ? s : s - numS;
-                const double v = s < numS ? vA[x] : vI[x];
-                if (v > llHMQ + DD_EPS) { llHMQ = v; mapHMQ = s; }
-            }
+            llOn = wave_max(on);
+            llOff = vA[0] > vI[0] ? vA[0] : vI[0];                          // states 0 and numS (:1104-1105); lane 0 only
+            slice_argmax<K>(vA, vI, x0, numS, bufA + D, bufI + 1, ll, mapRMQ);
+            slice_argmax<K>(hA, hI, x0, numS, bufA + D, bufI + 1, llHMQ, mapHMQ);
         }
+        STAMP(4);   // join
         const int xR = mapRMQ % numS, xH = mapHMQ % numS;
         const bool offHap = (xR == 0 || xR == RO);
         const bool offHapHMQ = (xH == 0 || xH == RO);
 
-        // ================= traceback: computeMAPState (:1148-1165), every lane redundantly =================
+        // ================= traceback: computeMAPState (:1148-1165).  The two chains (towards base 0 through
+        // btf, towards base L-1 through btb) are independent: step them in the same iteration so their LDS
+        // round trips overlap.  Every lane walks redundantly (wave-uniform); lane 0 records.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
-            int s = mapHMQ;
-            if (lane == 0) ms[bMid] = (int16_t)s;
-            for (int b = bMid; b > 0; b--) {                 // mapState[b-1] = btf[b][mapState[b]]
-                const bool ins = s >= numS;
-                const int x = ins ? s - numS : s;
-                const unsigned byte = bt[(size_t)b * NP + x];
-                const unsigned ch = byte & 15u;
-                int p;
-                if (ins) p = (byte & 16u) ? x : s;
-                else if (x == 0) p = 0;
-                else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
-                else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
-                s = p;
-                if (lane == 0) ms[b - 1] = (int16_t)s;
-            }
-            s = mapHMQ;
-            for (int b = bMid; b < L - 1; b++) {             // mapState[b+1] = btb[b][mapState[b]] (row b+1)
-                const bool ins = s >= numS;
-                const int x = ins ? s - numS : s;
-                const unsigned byte = bt[(size_t)(b + 1) * NP + x];
-                const unsigned ch = byte & 15u;
-                int p;
-                if (ins) p = (byte & 16u) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : s;
-                else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
-                else if (x == RO) p = (ch == 0) ? RO : numS + RO;
-                else p = (ch == 0) ? numS + x : x + (int)ch;
-                s = p;
-                if (lane == 0) ms[b + 1] = (int16_t)s;
+            int sL = mapHMQ, sR = mapHMQ;
+            if (lane == 0) ms[bMid] = (int16_t)mapHMQ;
+            const int nL = bMid, nR = L - 1 - bMid;
+            const int n = nL > nR ? nL : nR;
+            for (int i = 0; i < n; i++) {
+                if (i < nL) {                                 // mapState[b-1] = btf[b][mapState[b]]
+                    const int b = bMid - i;
+                    const bool ins = sL >= numS;
+                    const int x = ins ? sL - numS : sL;
+                    const unsigned byte = bt[(size_t)b * NP + x];
+                    const unsigned ch = byte & 15u;
+                    int p;
+                    if (ins) p = (byte & 16u) ? x : sL;
+                    else if (x == 0) p = 0;
+                    else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
+                    else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
+                    sL = p;
+                    if (lane == 0) ms[b - 1] = (int16_t)p;
+                }
+                if (i < nR) {                                 // mapState[b+1] = btb[b][mapState[b]] (stored at row b+1)
+                    const int b = bMid + i;
+                    const bool ins = sR >= numS;
+                    const int x = ins ? sR - numS : sR;
+                    const unsigned byte = bt[(size_t)(b + 1) * NP + x];
+                    const unsigned ch = byte & 15u;
+                    int p;
+                    if (ins) p = (byte & 16u) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
+                    else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
+                    else if (x == RO) p = (ch == 0) ? RO : numS + RO;
+                    else p = (ch == 0) ? numS + x : x + (int)ch;
+                    sR = p;
+                    if (lane == 0) ms[b + 1] = (int16_t)p;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        STAMP(5);   // traceback
         // ================= reportVariants (:1351-1475): hpos + QC counters, lane-parallel over read bases ====
-        int nIndel = 0, nMis = 0, nBQT = 0, nmmBQT = 0, nMML = 0, nMMR = 0;
-        int firstB = 0x7fffffff, lastB = -1;
+        int nIndel = 0, nMis = 0, nBQT = 0, nmmBQT = 0, nMML = 0, nMMR = 0;     // wave-uniform (ballot counts)
+        int firstB = 0x7fffffff, lastB = -1;                                   // per lane, reduced below
+        double mLogBQ = 0.0;
         const double thr = T[TC_BQT];
         int16_t *hp_out = P.out.hpos ? P.out.hpos + hpos_base + (so - rs_base) : nullptr;
         for (int b0 = 0; b0 < L; b0 += 64) {
             const int b = b0 + lane;
             double cb = 0.0;
+            bool pIndel = false, pDel = false, pMis = false, pBQT = false, pmmBQT = false, pL = false, pR = false;
             if (b < L) {
                 const int s = ms[b];
                 const bool ins = s >= numS;
@@ -509,52 +577,55 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                 else if (x == RO) hp = DD_HPOS_RO;
                 else if (ins) {
                     hp = DD_HPOS_INS;
-                    if (b == 0 || ms[b - 1] < numS) nIndel++;                     // start of an insertion run
+                    pIndel = (b == 0 || ms[b - 1] < numS);                      // start of an insertion run (:1379-1394)
                 } else {
                     hp = x - 1;
                     firstB = hp < firstB ? hp : firstB;
                     lastB = hp > lastB ? hp : lastB;
                     const int qi = rdQ[b];
-                    const double q = T[T_QUAL + 4 * qi + 3];
+                    const double q = shQ[4 * qi + 3];
                     const bool hiq = q > thr;
-                    if (hiq) { nBQT++; cb = T[T_QUAL + 4 * qi + 2]; }
-                    const int rc = rdC[b];
-                    if (rc != (int)sc[x]) {                                        // read.seq[b]!=hap.seq[s-1]
-                        if (hiq) nmmBQT++;
-                        if (b < 6) nMML++;
-                        if (b > L - 6) nMMR++;
-                        if (q > 0.95) nMis++;
+                    if (hiq) { pBQT = true; cb = shQ[4 * qi + 2]; }             // (:1404-1407)
+                    if ((int)rdC[b] != (int)sc[x]) {                            // read.seq[b]!=hap.seq[s-1] (:1410)
+                        pmmBQT = hiq;
+                        pL = b < 6;
+                        pR = b > L - 6;
+                        pMis = q > 0.95;
                     }
                     if (b < L - 1) {
                         const int ns = ms[b + 1];
-                        if (ns < numS && ns - s > 1) nIndel++;                     // deletion (:1437-1453)
+                        pDel = (ns < numS && ns - s > 1);                       // deletion (:1437-1453)
                     }
                 }
                 if (hp_out) hp_out[b] = (int16_t)hp;
             }
-            // contrib must not alias anything still needed: bt is dead after the traceback
-            if (b < L) contrib[b] = cb;
+            nIndel += __popcll(__ballot(pIndel)) + __popcll(__ballot(pDel));
+            nMis += __popcll(__ballot(pMis));
+            nmmBQT += __popcll(__ballot(pmmBQT));
+            nMML += __popcll(__ballot(pL));
+            nMMR += __popcll(__ballot(pR));
+            const unsigned long long bq = __ballot(pBQT);
+            nBQT += __popcll(bq);
+            // mLogBQ: the reference adds log10(1-q) base by base in read order (:1404-1407); fp64 + is not
+            // associative, so the sum runs serially over the lanes in order (adding +0.0 for skipped bases
+            // is exact).  Cross-lane reads through v_readlane: no LDS round trip per base.
+            if (bq) {
+                const int lo = __double2loint(cb), hi = __double2hiint(cb);
+                const int nb = (L - b0) < 64 ? (L - b0) : 64;
+                for (int i = 0; i < nb; i++) {
+                    const int l2 = __builtin_amdgcn_readlane(lo, i), h2 = __builtin_amdgcn_readlane(hi, i);
+                    mLogBQ += __hiloint2double(h2, l2);
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // integer reductions across the wave
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            nIndel += __shfl_xor(nIndel, off);
-            nMis += __shfl_xor(nMis, off);
-            nBQT += __shfl_xor(nBQT, off);
-            nmmBQT += __shfl_xor(nmmBQT, off);
-            nMML += __shfl_xor(nMML, off);
-            nMMR += __shfl_xor(nMMR, off);
             const int f = __shfl_xor(firstB, off), l2 = __shfl_xor(lastB, off);
             firstB = f < firstB ? f : firstB;
             lastB = l2 > lastB ? l2 : lastB;
         }
         if (firstB == 0x7fffffff) firstB = -1;
-        // mLogBQ: the reference adds log10(1-q) base by base in read order (:1404-1407); fp64 + is not
-        // associative, so sum serially (adding +0.0 for skipped bases is exact).
-        double mLogBQ = 0.0;
-        for (int b = 0; b < L; b++) mLogBQ += contrib[b];
+        STAMP(6);   // hpos + counters + mLogBQ
 
         // hapIndelCovered / hapSNPCovered (:1465-1472; AlignedVariant::isCovered Variant.hpp:125-128)
         if (P.out.var_covered && nv > 0) {
@@ -586,6 +657,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             if (P.out.firstBase) P.out.firstBase[pair] = (int16_t)firstB;
             if (P.out.lastBase) P.out.lastBase[pair] = (int16_t)lastB;
         }
+        STAMP(7);   // mLogBQ + coverage + scalar outputs
         // the next read reuses rdE/rdC/ms/bt of this wave: all of this pair's LDS reads precede (in program
         // order, same wave) the next pair's LDS writes, and DS ops of one wave execute in order.
     }
@@ -625,6 +697,13 @@ static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t l
     return hipGetLastError();
 }
 
+#ifdef DD_ONLY_K   // diagnostic builds: a single instantiation compiles in seconds
+hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+{
+    if (K != DD_ONLY_K || Dt != DD_ONLY_D) return hipErrorInvalidValue;
+    return launch_one<DD_ONLY_K, DD_ONLY_D>(A, dim3(grid), waves, lds, st);
+}
+#else
 template <int D>
 static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
@@ -650,6 +729,8 @@ hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int wav
     default: return hipErrorInvalidValue;
     }
 }
+
+#endif
 
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)
 {
