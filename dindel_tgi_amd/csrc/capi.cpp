@@ -61,13 +61,13 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, ddk::KernelArg
     const uint32_t NP = 64u * K;
     uint32_t o = 0;
     o = up16(NP + 16);
-    A.lds_off_E = o;  o += up16((NP + 2) * 8);
-    A.lds_off_N = o;  o += up16((NP + 2) * 8);
+    A.lds_off_E = o;  o += up16((NP + Dt + 2) * 8);
+    A.lds_off_N = o;  o += up16((NP + Dt + 2) * 8);
     A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
     A.n_qual = n_qual;
     A.lds_shared_bytes = o;
     uint32_t wv = 0;
-    A.lds_off_A = wv;   wv += up16((2 * Dt + NP) * 8);
+    A.lds_off_A = wv;   wv += up16((2 * Dt + NP) * 16);   // {value, emission} per state + pads
     A.lds_off_I = wv;   wv += up16((NP + 2) * 8);
     A.lds_off_rdE = wv; wv += up16(Lmax * 16);
     A.lds_off_rdC = wv; wv += up16(Lmax);

@@ -113,18 +113,6 @@ __device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double
 }
 
 template <int K, int D>
-struct LaneConst {
-    double lpn[K];        // Nn[x]               (Dec: logProbNoError[x])
-    double eIn[K];        // E[x]                (Dec: insertion-open into x)
-    double lpDec[K][D];   // y=1: Nn[x]; y>=2: E[x]+(y-1)*II
-    double cInc[K][D];    // (lp_y(src)+Nn[src]) for src=x+y
-    double eInc[K];       // E[x+1]              (Inc: insertion-open)
-    uint64_t mDec[K];     // bit c*D+(y-1): obs(state x-y) == eq for read column c
-    uint64_t mInc[K];     // bit c*D+(y-1): obs(state x+y) == eq for read column c
-    uint32_t mOwn[K];     // bit c: obs(state x) == eq
-};
-
-template <int K, int D>
 __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,13 +139,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
 
     // ---------------- shared (per haplotype) region ----------------
     unsigned char *sc = smem;                                   // [NP+16] state codes
-    double *shE = reinterpret_cast<double *>(smem + P.lds_off_E);  // [NP+2]
-    double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+2]
+    double *shE = reinterpret_cast<double *>(smem + P.lds_off_E);  // [NP+D+2] logProbError per state
+    double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+D+2] logProbNoError per state
     double *shQ = reinterpret_cast<double *>(smem + P.lds_off_Q);  // [n_qual][4] eq, uq, log10(1-q), q
     // ---------------- wave-private region ----------------
     unsigned char *wbase = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
-    double *bufA = reinterpret_cast<double *>(wbase + P.lds_off_A);       // [D + NP + D]   index s -> bufA[D+s]
-    double *bufI = reinterpret_cast<double *>(wbase + P.lds_off_I);       // [1 + NP + 1]   index s -> bufI[1+s]
+    // one HMM slice as the neighbours see it: {value, emission log of that state for the slice's read base}
+    double2 *rowA = reinterpret_cast<double2 *>(wbase + P.lds_off_A);     // [D + NP + D]   state s -> rowA[D+s]
+    double *rowI = reinterpret_cast<double *>(wbase + P.lds_off_I);       // [1 + NP + 1]   state s -> rowI[1+s]
     double *rdE = reinterpret_cast<double *>(wbase + P.lds_off_rdE);      // [Lmax][2]  eq, uq per read base
     unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
     unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
@@ -169,11 +158,11 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     // ---- per-haplotype setup: state codes + homopolymer indel-error logs (setupTransitionProbs :1675-1703)
     for (int s = tid; s < NP + 16; s += nthr) {
         int code = 6;                                // padded state: matches nothing
-        if (s == 0 || s == RO) code = 4;
+        if (s == 0 || s == RO) code = 4;             // LO / RO: emission is always eq (:237-241)
         else if (s < RO) code = base_code((unsigned char)P.hap_seq[hs_off + s - 1]);
         sc[s] = (unsigned char)code;
     }
-    for (int s = tid; s < NP + 2; s += nthr) {
+    for (int s = tid; s < NP + D + 2; s += nthr) {
         shE[s] = T[TC_EDEF];
         shN[s] = T[TC_NDEF];
     }
@@ -202,50 +191,30 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     }
     __syncthreads();
 
-    // ---- per-lane register constants for this haplotype ----
-    LaneConst<K, D> C;
+    // ---- per-lane register constants for this haplotype (states past RO are switched off with -inf) ----
     const int x0 = lane * K;
     const int laneRO = RO / K, kRO = RO - laneRO * K;
+    double lpn[K], eIn[K], eInc[K], niDec[K];
+    uint32_t mOwn[K];                               // bit c: this state's emission is eq for read column c
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int x = x0 + k;
         const bool valid = x < numS;
-        const double Ek = valid ? shE[x] : NEG_INF;
-        const double Nk = valid ? shN[x] : NEG_INF;
-        C.lpn[k] = Nk;
-        C.eIn[k] = Ek;
-        uint64_t md = 0, mi = 0;
-#pragma unroll
-        for (int y = 1; y <= D; y++) {
-            C.lpDec[k][y - 1] = (y > Dr) ? NEG_INF : (y == 1 ? Nk : Ek + (double)(y - 1) * II);
-            const int src = x + y;
-            double c = NEG_INF;
-            if (src <= RO && y <= Dr) {
-                const double Es = shE[src], Ns = shN[src];
-                const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
-                c = lp + Ns;
-            }
-            C.cInc[k][y - 1] = c;
-#pragma unroll
-            for (int col = 0; col < 5; col++) {
-                if (x - y >= 0 && code_match(sc[x - y], col)) md |= 1ull << (col * D + (y - 1));
-                if (src <= RO && code_match(sc[src], col)) mi |= 1ull << (col * D + (y - 1));
-            }
-        }
-        C.mDec[k] = md;
-        C.mInc[k] = mi;
+        lpn[k] = valid ? shN[x] : NEG_INF;          // Dec: logProbNoError[x]
+        eIn[k] = valid ? shE[x] : NEG_INF;          // Dec: logProbError[x]   (insertion-open into x)
+        eInc[k] = (x + 1 <= RO) ? shE[x + 1] : NEG_INF;   // Inc: logProbError[x+1]
+        niDec[k] = (x == 0) ? NEG_INF : NI;         // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
         uint32_t mo = 0;
 #pragma unroll
         for (int col = 0; col < 5; col++)
             if (valid && code_match(sc[x], col)) mo |= 1u << col;
-        C.mOwn[k] = mo;
-        C.eInc[k] = (x + 1 <= RO) ? shE[x + 1] : NEG_INF;
+        mOwn[k] = mo;
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
 
     // pads of the wave-private rows: written once, never touched again
-    if (lane < D) { bufA[lane] = NEG_INF; bufA[D + NP + lane] = NEG_INF; }
-    if (lane == 0) { bufI[0] = NEG_INF; bufI[1 + NP] = NEG_INF; }
+    if (lane < D) { rowA[lane] = make_double2(NEG_INF, 0.0); rowA[D + NP + lane] = make_double2(NEG_INF, 0.0); }
+    if (lane == 0) { rowI[0] = NEG_INF; rowI[1 + NP] = NEG_INF; }
 
     const int64_t pair_base = P.win_pair_off[w] + (int64_t)(g - h0) * R;
     const int rs_base = P.read_seq_off[r0];
@@ -254,7 +223,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     const int nv = P.hap_var_off ? (P.hap_var_off[g + 1] - P.hap_var_off[g]) : 0;
 
     STAMP_INIT;
-    STAMP(0);   // per-haplotype setup
+    STAMP(0);
     // ======================= loop over this wave's reads =======================
     for (int ri = split * nwav + wave; ri < R; ri += P.n_split * nwav) {
         const int r = r0 + ri;
@@ -309,79 +278,98 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             a[k] = valid ? 0.0 : NEG_INF;      // alpha[0][*] = 0 (:335-338)
             in[k] = valid ? 0.0 : NEG_INF;
         }
-        for (int b = 1; b <= bMid; b++) {
-            // publish slice b-1 for the neighbours
-#pragma unroll
-            for (int k = 0; k < K; k++) { bufA[D + x0 + k] = a[k]; bufI[1 + x0 + k] = in[k]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
-            const int col = rdC[b - 1] > 4 ? 4 : rdC[b - 1];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double v[D + K];
-#pragma unroll
-            for (int j = 0; j < D; j++) v[j] = bufA[x0 + j];       // A[x0-D+j]
-#pragma unroll
-            for (int k = 0; k < K; k++) v[D + k] = a[k];
-            const double im1 = bufI[x0];                            // I[x0-1]
-            double na[K], ni[K];
-            unsigned btb[K];
+        {
+            double lpDec[K][D];               // y=1: Nn[x]; y>=2: E[x]+(y-1)*II   (:1786-1791)
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const uint32_t mb = (uint32_t)(C.mDec[k] >> (col * D));
-                double best = ((((mb & 1u) ? eq : uq) + C.lpDec[k][0]) + v[D + k - 1]) + C.lpn[k];
-                unsigned ch = 1;
+                lpDec[k][0] = lpn[k];
 #pragma unroll
-                for (int y = 2; y <= D; y++) {
-                    const double o = ((mb >> (y - 1)) & 1u) ? eq : uq;
-                    const double val = ((o + C.lpDec[k][y - 1]) + v[D + k - y]) + C.lpn[k];
-                    const bool take = val >= best;                 // newIdx < destIdx: branch 2 of updateMax
-                    best = take ? val : best;
-                    ch = take ? (unsigned)y : ch;
-                }
-                {
-                    const double ip = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
-                    const double val = (eq + ip) + C.eIn[k];       // from inserted state numS+x-1 (:1807-1811)
-                    const bool take = val > best + DD_EPS;
-                    best = take ? val : best;
-                    ch = take ? 0u : ch;
-                }
-                na[k] = best;
-                const double d = (eq + in[k]) + II;                // (:1816-1820)
-                const double o = ((C.mOwn[k] >> col) & 1u) ? eq : uq;
-                const double val = (o + a[k]) + NI;                // (:1823-1826)
-                const bool take = val >= d;
-                ni[k] = take ? val : d;
-                btb[k] = ch | (take ? 16u : 0u);
+                for (int y = 2; y <= D; y++) lpDec[k][y - 1] = (y > Dr) ? NEG_INF : eIn[k] + (double)(y - 1) * II;
             }
-            if (lane == 0) {                                        // x = 0  (:1798-1799, :1816)
-                na[0] = (eq + a[0]) + NN;
-                ni[0] = (eq + in[0]) + II;
-                btb[0] = 0;
-            }
-            if (lane == laneRO) {                                   // x = RO (:1780-1782, :1804-1805)
+            for (int b = 1; b <= bMid; b++) {
+                const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
+                const int col = rdC[b - 1] > 4 ? 4 : rdC[b - 1];
+                double v[D + K], ov[D + K];
+                // publish slice b-1 (value + this state's emission for read base b-1) for the neighbours
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    if (k == kRO) {
-                        const double aHs = v[D + k - 1];
-                        const double iHs = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
-                        const uint32_t mb = (uint32_t)(C.mDec[k] >> (col * D));
-                        const double oHs = (mb & 1u) ? eq : uq;
-                        double best = NEG_INF;
-                        int idx = 0, code = 0;
-                        update_max(best, idx, code, ((eq + a[k]) + lLL) + NN, RO, 0);
-                        update_max(best, idx, code, ((oHs + aHs) + lFL) + NN, Hs, 1);
-                        update_max(best, idx, code, ((eq + in[k]) + lLL) + E_RO, numS + RO, 2);
-                        update_max(best, idx, code, ((eq + iHs) + lFL) + E_Hs, numS + Hs, 3);
-                        na[k] = best;
-                        btb[k] = (btb[k] & 16u) | (unsigned)code;
+                    ov[D + k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
+                    v[D + k] = a[k];
+                    rowA[D + x0 + k] = make_double2(a[k], ov[D + k]);
+                    rowI[1 + x0 + k] = in[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int j = 0; j < D; j++) {                      // states x0-D .. x0-1
+                    const double2 t = rowA[x0 + j];
+                    v[j] = t.x;
+                    ov[j] = t.y;
+                }
+                const double im1 = rowI[x0];                        // I[x0-1]
+                double na[K], ni[K];
+                unsigned btb[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double best = ((ov[D + k - 1] + lpDec[k][0]) + v[D + k - 1]) + lpn[k];    // (:1793), y = 1
+                    unsigned ch = 1;
+#pragma unroll
+                    for (int y = 2; y <= D; y++) {
+                        const double val = ((ov[D + k - y] + lpDec[k][y - 1]) + v[D + k - y]) + lpn[k];
+                        const bool take = val >= best;             // newIdx < destIdx: either branch of updateMax
+                        best = __builtin_fmax(best, val);
+                        ch = take ? (unsigned)y : ch;
+                    }
+                    {
+                        const double ip = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
+                        const double val = (eq + ip) + eIn[k];     // from inserted state numS+x-1 (:1807-1811)
+                        const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
+                        best = take ? val : best;
+                        ch = take ? 0u : ch;
+                    }
+                    na[k] = best;
+                    const double d = (eq + in[k]) + II;            // stay inserted (:1816-1820)
+                    const double val = (ov[D + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
+                    const bool take = val >= d;
+                    ni[k] = __builtin_fmax(d, val);
+                    btb[k] = ch | (take ? 16u : 0u);
+                }
+                if (lane == 0) {                                    // x = 0 (:1798-1799)
+                    na[0] = (eq + a[0]) + NN;
+                    btb[0] = 0;
+                }
+                if (lane == laneRO) {                               // x = RO (:1780-1782, :1804-1805)
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if (k == kRO) {
+                            const double aHs = v[D + k - 1], oHs = ov[D + k - 1];
+                            const double iHs = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
+                            // candidate order and indices: RO, Hs (< RO), numS+RO (largest), numS+Hs
+                            double best = ((eq + a[k]) + lLL) + NN;
+                            unsigned code = 0;
+                            const double c2 = ((oHs + aHs) + lFL) + NN;
+                            const bool t2 = c2 >= best;            // smaller index: either branch
+                            best = __builtin_fmax(best, c2);
+                            code = t2 ? 1u : code;
+                            const double c3 = ((eq + in[k]) + lLL) + E_RO;
+                            const bool t3 = c3 > best + DD_EPS;    // larger index: branch 1 only
+                            best = t3 ? c3 : best;
+                            code = t3 ? 2u : code;
+                            const double c4 = ((eq + iHs) + lFL) + E_Hs;
+                            const bool t4 = (c4 > best + DD_EPS) || (t3 && c4 >= best);   // numS+Hs < numS+RO only
+                            best = t4 ? c4 : best;
+                            code = t4 ? 3u : code;
+                            na[k] = best;
+                            btb[k] = (btb[k] & 16u) | code;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                a[k] = na[k];
-                in[k] = ni[k];
-                bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];
+                for (int k = 0; k < K; k++) {
+                    a[k] = na[k];
+                    in[k] = ni[k];
+                    bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];
+                }
             }
         }
         STAMP(2);   // Dec passes
@@ -396,85 +384,105 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             a[k] = valid ? 0.0 : NEG_INF;      // beta[L-1][*] = 0
             in[k] = valid ? 0.0 : NEG_INF;
         }
-        for (int b = L - 1; b > bMid; b--) {
-#pragma unroll
-            for (int k = 0; k < K; k++) bufA[D + x0 + k] = a[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
-            const int col = rdC[b] > 4 ? 4 : rdC[b];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double v[D + K];
-#pragma unroll
-            for (int k = 0; k < K; k++) v[k] = a[k];
-#pragma unroll
-            for (int j = 0; j < D; j++) v[K + j] = bufA[D + x0 + K + j];   // B[x0+K+j]
-            double na[K], ni[K];
-            unsigned btb[K];
+        {
+            double cInc[K][D];                 // lp_y(src)+Nn[src] for src = x+y  (:1730-1735)
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const uint32_t mb = (uint32_t)(C.mInc[k] >> (col * D));
-                double best = (C.cInc[k][0] + v[k + 1]) + ((mb & 1u) ? eq : uq);
-                unsigned ch = 1;
 #pragma unroll
-                for (int y = 2; y <= D; y++) {
-                    const double o = ((mb >> (y - 1)) & 1u) ? eq : uq;
-                    const double val = (C.cInc[k][y - 1] + v[k + y]) + o;  // lp+lpn+beta+obs (:1735)
-                    const bool take = val > best + DD_EPS;                  // newIdx > destIdx: branch 1 only
-                    best = take ? val : best;
-                    ch = take ? (unsigned)y : ch;
+                for (int y = 1; y <= D; y++) {
+                    const int src = x0 + k + y;
+                    const double Es = shE[src], Ns = shN[src];
+                    const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
+                    cInc[k][y - 1] = (src <= RO && y <= Dr) ? lp + Ns : NEG_INF;
                 }
-                {
-                    const double val = (eq + in[k]) + C.eInc[k];            // to inserted state numS+x (:1746-1749)
-                    const bool take = val > best + DD_EPS;
-                    best = take ? val : best;
-                    ch = take ? 0u : ch;
-                }
-                na[k] = best;
-                const double d = (eq + in[k]) + II;                         // (:1754-1758)
-                const double val = (((mb & 1u) ? eq : uq) + v[k + 1]) + NI; // src = x+1 (:1763-1767)
-                const bool take = val >= d;
-                ni[k] = take ? val : d;
-                btb[k] = ch | (take ? 16u : 0u);
             }
-            if (lane == 0) {                                                 // x = 0 (:1720-1722, :1746-1749, :1762)
-                const uint32_t mb = (uint32_t)(C.mInc[0] >> (col * D));
-                double best = NEG_INF;
-                int idx = 0, code = 0;
-                update_max(best, idx, code, ((eq + a[0]) + lLL) + NN, 0, 0);
-                update_max(best, idx, code, ((((mb & 1u) ? eq : uq) + v[1]) + lFL) + NN, 1, 1);
-                update_max(best, idx, code, (eq + in[0]) + E_1, numS + 0, 2);
-                na[0] = best;
-                const double d = (eq + in[0]) + II;
-                const double val = (eq + a[0]) + NI;
-                const bool take = val >= d;
-                ni[0] = take ? val : d;
-                btb[0] = (unsigned)code | (take ? 16u : 0u);
-            }
-            if (lane == laneRO) {                                            // x = RO (:1741-1742, :1750, :1763-1767)
+            for (int b = L - 1; b > bMid; b--) {
+                const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
+                const int col = rdC[b] > 4 ? 4 : rdC[b];
+                double v[D + K], ov[D + K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    if (k == kRO) {
-                        double best = NEG_INF;
-                        int idx = 0, code = 0;
-                        update_max(best, idx, code, (eq + a[k]) + Nn_RO, RO, 0);
-                        update_max(best, idx, code, (eq + in[k]), numS + RO, 1);
-                        na[k] = best;
-                        const double d = (eq + in[k]) + II;
-                        const double val = (eq + a[k]) + NI;
-                        const bool take = val >= d;
-                        ni[k] = take ? val : d;
-                        btb[k] = (unsigned)code | (take ? 16u : 0u);
+                    ov[k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
+                    v[k] = a[k];
+                    rowA[D + x0 + k] = make_double2(a[k], ov[k]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int j = 0; j < D; j++) {                      // states x0+K .. x0+K+D-1
+                    const double2 t = rowA[D + x0 + K + j];
+                    v[K + j] = t.x;
+                    ov[K + j] = t.y;
+                }
+                double na[K], ni[K];
+                unsigned btb[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double best = (cInc[k][0] + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
+                    unsigned ch = 1;
+#pragma unroll
+                    for (int y = 2; y <= D; y++) {
+                        const double val = (cInc[k][y - 1] + v[k + y]) + ov[k + y];
+                        const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
+                        best = take ? val : best;
+                        ch = take ? (unsigned)y : ch;
+                    }
+                    {
+                        const double val = (eq + in[k]) + eInc[k]; // to inserted state numS+x (:1746-1749)
+                        const bool take = val > best + DD_EPS;
+                        best = take ? val : best;
+                        ch = take ? 0u : ch;
+                    }
+                    na[k] = best;
+                    const double d = (eq + in[k]) + II;            // (:1754-1758)
+                    const double val = (ov[k + 1] + v[k + 1]) + NI;   // src = x+1 (:1763-1767)
+                    const bool take = val >= d;
+                    ni[k] = __builtin_fmax(d, val);
+                    btb[k] = ch | (take ? 16u : 0u);
+                }
+                if (lane == 0) {                                    // x = 0 (:1720-1722, :1746-1749, :1762)
+                    double best = ((eq + a[0]) + lLL) + NN;         // idx 0
+                    unsigned code = 0;
+                    const double c2 = ((ov[1] + v[1]) + lFL) + NN;  // idx 1
+                    const bool t2 = c2 > best + DD_EPS;
+                    best = t2 ? c2 : best;
+                    code = t2 ? 1u : code;
+                    const double c3 = (eq + in[0]) + E_1;           // idx numS
+                    const bool t3 = c3 > best + DD_EPS;
+                    best = t3 ? c3 : best;
+                    code = t3 ? 2u : code;
+                    na[0] = best;
+                    const double d = (eq + in[0]) + II;
+                    const double val = (eq + a[0]) + NI;
+                    const bool take = val >= d;
+                    ni[0] = __builtin_fmax(d, val);
+                    btb[0] = code | (take ? 16u : 0u);
+                }
+                if (lane == laneRO) {                               // x = RO (:1741-1742, :1750, :1763-1767)
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if (k == kRO) {
+                            double best = (eq + a[k]) + Nn_RO;      // idx RO
+                            const double c2 = eq + in[k];           // idx numS+RO
+                            const bool t2 = c2 > best + DD_EPS;
+                            best = t2 ? c2 : best;
+                            na[k] = best;
+                            const double d = (eq + in[k]) + II;
+                            const double val = (eq + a[k]) + NI;
+                            const bool take = val >= d;
+                            ni[k] = __builtin_fmax(d, val);
+                            btb[k] = (t2 ? 1u : 0u) | (take ? 16u : 0u);
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                a[k] = na[k];
-                in[k] = ni[k];
-                bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];    // btb[b-1] stored at row b
+                for (int k = 0; k < K; k++) {
+                    a[k] = na[k];
+                    in[k] = ni[k];
+                    bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];    // btb[b-1] stored at row b
+                }
             }
         }
-
         STAMP(3);   // Inc passes
         // ================= join at bMid: calcLikelihoodFromLastSlice (:1075-1144) + computeBMidPrior (:268-305)
         double ll, llHMQ, llOff, llOn;
@@ -487,11 +495,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             const double prOn0 = T[T_MAPQ + 4 * mqi + 2], prOn1 = T[T_MAPQ + 4 * mqi + 3];
             const double hqOff0 = T[TC_HMQ + 0], hqOff1 = T[TC_HMQ + 1], hqOn0 = T[TC_HMQ + 2], hqOn1 = T[TC_HMQ + 3];
             double vA[K], vI[K], hA[K], hI[K];
+            double *scanA = reinterpret_cast<double *>(rowA + D), *scanI = scanA + NP;   // near-tie replay scratch (row is free now)
             double on = NEG_INF;
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int x = x0 + k;
-                const double o = ((C.mOwn[k] >> col) & 1u) ? eq : uq;
+                const double o = ((mOwn[k] >> col) & 1u) ? eq : uq;
                 const double baseA = (al_a[k] + o) + a[k];             // alpha + obs + beta (:1098)
                 const double baseI = (al_i[k] + eq) + in[k];
                 vA[k] = baseA + ((x == 0) ? prOff0 : (x == RO ? -100.0 : prOn0));    // read's mapping quality
@@ -505,8 +514,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
             }
             llOn = wave_max(on);
             llOff = vA[0] > vI[0] ? vA[0] : vI[0];                          // states 0 and numS (:1104-1105); lane 0 only
-            slice_argmax<K>(vA, vI, x0, numS, bufA + D, bufI + 1, ll, mapRMQ);
-            slice_argmax<K>(hA, hI, x0, numS, bufA + D, bufI + 1, llHMQ, mapHMQ);
+            slice_argmax<K>(vA, vI, x0, numS, scanA, scanI, ll, mapRMQ);
+            slice_argmax<K>(hA, hI, x0, numS, scanA, scanI, llHMQ, mapHMQ);
         }
         STAMP(4);   // join
         const int xR = mapRMQ % numS, xH = mapHMQ % numS;
