@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdindel_hmm.so")
+# DD_LIB_PATH: A/B a diagnostic build of the SAME library (tools/); never a different implementation
+LIB_PATH = os.environ.get("DD_LIB_PATH") or os.path.join(_HERE, "csrc", "libdindel_hmm.so")
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)

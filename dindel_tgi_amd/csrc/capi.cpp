@@ -73,7 +73,11 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, ddk::KernelArg
     A.lds_off_rdC = wv; wv += up16(Lmax);
     A.lds_off_rdQ = wv; wv += up16(Lmax);
     A.lds_off_ms = wv;  wv += up16(Lmax * 2);
-    A.lds_off_bt = wv;  wv += up16((uint32_t)Lmax * NP);
+    {   // packed back-pointers: one word of K*(CB+1) bits per lane per read base (BtPack in hmm_kernel.hip)
+        const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
+        const uint32_t bytes = bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+        A.lds_off_bt = wv;  wv += up16((uint32_t)Lmax * 64u * bytes);
+    }
     A.lds_wave_bytes = wv;
     return (size_t)A.lds_shared_bytes + (size_t)waves * wv;
 }

@@ -112,8 +112,28 @@ __device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Back-pointer packing: per position CB bits of transition choice (0 = from the inserted state, y = jump
+// length; LO/RO use their own small codes) + 1 bit for the inserted state's choice.  D <= 7 -> 4 bits per
+// position, else 5.  One lane's K positions of one slice go into one 1/2/4/8-byte word in LDS.
+template <int K, int D> struct BtPack {
+    static constexpr int CB = (D <= 7) ? 3 : 4;
+    static constexpr int PB = CB + 1;
+    static constexpr int BITS = K * PB;
+    static constexpr int BYTES = BITS <= 8 ? 1 : BITS <= 16 ? 2 : BITS <= 32 ? 4 : 8;
+};
+template <int BYTES> struct BtWord;
+template <> struct BtWord<1> { typedef uint8_t type; };
+template <> struct BtWord<2> { typedef uint16_t type; };
+template <> struct BtWord<4> { typedef uint32_t type; };
+template <> struct BtWord<8> { typedef uint64_t type; };
+
+// Occupancy target (waves per SIMD) the register allocator is held to: measured +20 % going from 2 to 3
+// waves/SIMD at K<=2 (the VALU is the bound and two waves cannot keep it issuing).
+#ifndef DD_MIN_WAVES_PER_SIMD
+#define DD_MIN_WAVES_PER_SIMD(K) ((K) <= 2 ? 3 : 1)
+#endif
 template <int K, int D>
-__global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs P)
+__global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -151,7 +171,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
     unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
     unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
-    unsigned char *bt = wbase + P.lds_off_bt;                              // [Lmax][NP] back-pointers
+    typedef BtPack<K, D> BP;
+    typedef typename BtWord<BP::BYTES>::type btword_t;
+    btword_t *bt = reinterpret_cast<btword_t *>(wbase + P.lds_off_bt);    // [Lmax][64] packed back-pointers
 
     const bool hap_ok = (P.maxLengthDel <= Hs);     // else "hapSize error." (ObservationModelFB.cpp:47)
 
@@ -332,7 +354,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                     const double val = (ov[D + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
                     const bool take = val >= d;
                     ni[k] = __builtin_fmax(d, val);
-                    btb[k] = ch | (take ? 16u : 0u);
+                    btb[k] = ch | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == 0) {                                    // x = 0 (:1798-1799)
                     na[0] = (eq + a[0]) + NN;
@@ -360,16 +382,18 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                             best = t4 ? c4 : best;
                             code = t4 ? 3u : code;
                             na[k] = best;
-                            btb[k] = (btb[k] & 16u) | code;
+                            btb[k] = (btb[k] & (1u << BP::CB)) | code;
                         }
                     }
                 }
+                btword_t word = 0;
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];
+                    word |= (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
+                bt[b * 64 + lane] = word;
             }
         }
         STAMP(2);   // Dec passes
@@ -438,7 +462,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                     const double val = (ov[k + 1] + v[k + 1]) + NI;   // src = x+1 (:1763-1767)
                     const bool take = val >= d;
                     ni[k] = __builtin_fmax(d, val);
-                    btb[k] = ch | (take ? 16u : 0u);
+                    btb[k] = ch | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == 0) {                                    // x = 0 (:1720-1722, :1746-1749, :1762)
                     double best = ((eq + a[0]) + lLL) + NN;         // idx 0
@@ -456,7 +480,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                     const double val = (eq + a[0]) + NI;
                     const bool take = val >= d;
                     ni[0] = __builtin_fmax(d, val);
-                    btb[0] = code | (take ? 16u : 0u);
+                    btb[0] = code | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == laneRO) {                               // x = RO (:1741-1742, :1750, :1763-1767)
 #pragma unroll
@@ -471,16 +495,18 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                             const double val = (eq + a[k]) + NI;
                             const bool take = val >= d;
                             ni[k] = __builtin_fmax(d, val);
-                            btb[k] = (t2 ? 1u : 0u) | (take ? 16u : 0u);
+                            btb[k] = (t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u);
                         }
                     }
                 }
+                btword_t word = 0;
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    bt[(size_t)b * NP + x0 + k] = (unsigned char)btb[k];    // btb[b-1] stored at row b
+                    word |= (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
+                bt[b * 64 + lane] = word;                           // btb[b-1] stored at row b
             }
         }
         STAMP(3);   // Inc passes
@@ -537,10 +563,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                     const int b = bMid - i;
                     const bool ins = sL >= numS;
                     const int x = ins ? sL - numS : sL;
-                    const unsigned byte = bt[(size_t)b * NP + x];
-                    const unsigned ch = byte & 15u;
+                    const unsigned byte = (unsigned)(bt[b * 64 + x / K] >> ((x % K) * BP::PB));
+                    const unsigned ch = byte & ((1u << BP::CB) - 1u);
                     int p;
-                    if (ins) p = (byte & 16u) ? x : sL;
+                    if (ins) p = (byte & (1u << BP::CB)) ? x : sL;
                     else if (x == 0) p = 0;
                     else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
                     else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
@@ -551,10 +577,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64) dd_hmm_kernel(const KernelArgs 
                     const int b = bMid + i;
                     const bool ins = sR >= numS;
                     const int x = ins ? sR - numS : sR;
-                    const unsigned byte = bt[(size_t)(b + 1) * NP + x];
-                    const unsigned ch = byte & 15u;
+                    const unsigned byte = (unsigned)(bt[(b + 1) * 64 + x / K] >> ((x % K) * BP::PB));
+                    const unsigned ch = byte & ((1u << BP::CB) - 1u);
                     int p;
-                    if (ins) p = (byte & 16u) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
+                    if (ins) p = (byte & (1u << BP::CB)) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
                     else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
                     else if (x == RO) p = (ch == 0) ? RO : numS + RO;
                     else p = (ch == 0) ? numS + x : x + (int)ch;
