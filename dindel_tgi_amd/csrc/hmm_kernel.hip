@@ -62,6 +62,15 @@ __device__ __forceinline__ void update_max(double &dest, int &idx, int &code, do
     else if (v >= dest && v <= dest + 1e-5 && idx > newIdx) { dest = v; idx = newIdx; code = newCode; }
 }
 
+// max of two non-NaN doubles as ONE v_max_f64 (the generic fmax lowering may add canonicalising self-max
+// instructions in IEEE mode)
+__device__ __forceinline__ double dmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
@@ -138,7 +147,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave index is uniform across the 64 lanes: tell the compiler, so that everything per read (offsets,
+    // lengths, bMid, loop counters, the traceback chain) lives on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 4, 2 or 1 waves (host picks what fits LDS)
 
     const int g = blockIdx.x / P.n_split;          // global haplotype index
@@ -339,7 +350,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                     for (int y = 2; y <= D; y++) {
                         const double val = ((ov[D + k - y] + lpDec[k][y - 1]) + v[D + k - y]) + lpn[k];
                         const bool take = val >= best;             // newIdx < destIdx: either branch of updateMax
-                        best = __builtin_fmax(best, val);
+                        best = dmax(best, val);
                         ch = take ? (unsigned)y : ch;
                     }
                     {
@@ -353,7 +364,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                     const double d = (eq + in[k]) + II;            // stay inserted (:1816-1820)
                     const double val = (ov[D + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
                     const bool take = val >= d;
-                    ni[k] = __builtin_fmax(d, val);
+                    ni[k] = dmax(d, val);
                     btb[k] = ch | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == 0) {                                    // x = 0 (:1798-1799)
@@ -371,7 +382,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                             unsigned code = 0;
                             const double c2 = ((oHs + aHs) + lFL) + NN;
                             const bool t2 = c2 >= best;            // smaller index: either branch
-                            best = __builtin_fmax(best, c2);
+                            best = dmax(best, c2);
                             code = t2 ? 1u : code;
                             const double c3 = ((eq + in[k]) + lLL) + E_RO;
                             const bool t3 = c3 > best + DD_EPS;    // larger index: branch 1 only
@@ -461,7 +472,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                     const double d = (eq + in[k]) + II;            // (:1754-1758)
                     const double val = (ov[k + 1] + v[k + 1]) + NI;   // src = x+1 (:1763-1767)
                     const bool take = val >= d;
-                    ni[k] = __builtin_fmax(d, val);
+                    ni[k] = dmax(d, val);
                     btb[k] = ch | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == 0) {                                    // x = 0 (:1720-1722, :1746-1749, :1762)
@@ -479,7 +490,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                     const double d = (eq + in[0]) + II;
                     const double val = (eq + a[0]) + NI;
                     const bool take = val >= d;
-                    ni[0] = __builtin_fmax(d, val);
+                    ni[0] = dmax(d, val);
                     btb[0] = code | (take ? (1u << BP::CB) : 0u);
                 }
                 if (lane == laneRO) {                               // x = RO (:1741-1742, :1750, :1763-1767)
@@ -494,7 +505,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                             const double d = (eq + in[k]) + II;
                             const double val = (eq + a[k]) + NI;
                             const bool take = val >= d;
-                            ni[k] = __builtin_fmax(d, val);
+                            ni[k] = dmax(d, val);
                             btb[k] = (t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u);
                         }
                     }
@@ -554,19 +565,30 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
-            int sL = mapHMQ, sR = mapHMQ;
-            if (lane == 0) ms[bMid] = (int16_t)mapHMQ;
+            // the chain is wave-uniform: keep it on the scalar unit (readfirstlane) so the ~L dependent steps
+            // cost no VALU issue slots beyond the LDS address move and the recorded state
+            int sL = __builtin_amdgcn_readfirstlane(mapHMQ), sR = sL;
+            if (lane == 0) ms[bMid] = (int16_t)sL;
             const int nL = bMid, nR = L - 1 - bMid;
             const int n = nL > nR ? nL : nR;
+            const unsigned chmask = (1u << BP::CB) - 1u, insbit = 1u << BP::CB;
             for (int i = 0; i < n; i++) {
                 if (i < nL) {                                 // mapState[b-1] = btf[b][mapState[b]]
                     const int b = bMid - i;
                     const bool ins = sL >= numS;
                     const int x = ins ? sL - numS : sL;
-                    const unsigned byte = (unsigned)(bt[b * 64 + x / K] >> ((x % K) * BP::PB));
-                    const unsigned ch = byte & ((1u << BP::CB) - 1u);
+                    const btword_t wv = bt[b * 64 + x / K];
+                    unsigned byte;
+                    if (sizeof(btword_t) == 8) {
+                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(wv & 0xffffffffu));
+                        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)wv >> 32));
+                        byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
+                    } else {
+                        byte = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)wv) >> ((x % K) * BP::PB);
+                    }
+                    const unsigned ch = byte & chmask;
                     int p;
-                    if (ins) p = (byte & (1u << BP::CB)) ? x : sL;
+                    if (ins) p = (byte & insbit) ? x : sL;
                     else if (x == 0) p = 0;
                     else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
                     else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
@@ -577,10 +599,18 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
                     const int b = bMid + i;
                     const bool ins = sR >= numS;
                     const int x = ins ? sR - numS : sR;
-                    const unsigned byte = (unsigned)(bt[(b + 1) * 64 + x / K] >> ((x % K) * BP::PB));
-                    const unsigned ch = byte & ((1u << BP::CB) - 1u);
+                    const btword_t wv = bt[(b + 1) * 64 + x / K];
+                    unsigned byte;
+                    if (sizeof(btword_t) == 8) {
+                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(wv & 0xffffffffu));
+                        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)wv >> 32));
+                        byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
+                    } else {
+                        byte = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)wv) >> ((x % K) * BP::PB);
+                    }
+                    const unsigned ch = byte & chmask;
                     int p;
-                    if (ins) p = (byte & (1u << BP::CB)) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
+                    if (ins) p = (byte & insbit) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
                     else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
                     else if (x == RO) p = (ch == 0) ? RO : numS + RO;
                     else p = (ch == 0) ? numS + x : x + (int)ch;
