@@ -46,7 +46,7 @@ def cpu_baseline(pb, params, seconds_target=15.0):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
     from tests import _oracle
     threads = max(1, min(16, os.cpu_count() or 1))
-    n_win = min(pb.n_windows, 2)
+    n_win = min(pb.n_windows, 2 * threads)          # calibration pass: every thread busy
     t0 = time.time()
     _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win)
     dt = time.time() - t0

@@ -1,0 +1,228 @@
+// compute_likelihoods.cpp — see compute_likelihoods.hpp.
+#include "compute_likelihoods.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include "../../include/dindel_hmm.h"
+
+namespace dindel {
+
+double Read::phredToProb(double phred)
+{   // reference Read.hpp:127-131 / 143-148
+    double q = (1.0 - pow(10.0, -phred / 10.0));
+    if (q < 0.0 || q > 1.0 || std::isnan(q) || std::isinf(q)) throw std::string("Phred error.");
+    if (q < 1e-16) q = 1e-16;
+    if (q > 1.0 - 1e-16) q = 1.0 - 1e-16;
+    return q;
+}
+
+static dd_params to_abi(const ObservationModelParameters &o)
+{
+    dd_params p;
+    p.pError = o.pError; p.pMut = o.pMut; p.pFirstgLO = o.pFirstgLO; p.mapQualThreshold = o.mapQualThreshold;
+    p.checkBaseQualThreshold = o.checkBaseQualThreshold; p.maxLengthDel = o.maxLengthDel; p.padCover = o.padCover;
+    p.bMid = o.bMid; p.forceReadOnHaplotype = o.forceReadOnHaplotype ? 1 : 0; p.mapUnmappedReads = o.mapUnmappedReads ? 1 : 0;
+    return p;
+}
+
+// Rebuilds what reportVariants derives from mapState (reference ObservationModelFB.cpp:1351-1475), from
+// hpos: >=0 haplotype index, -1 INS, -3 LO, -4 RO.  An insertion run is keyed at the haplotype position of
+// the inserted state; hpos does not carry it, but it equals (next on-haplotype base) or (previous + 1).
+void LikelihoodEngine::rebuildAlignment(const Haplotype &hap, const Read &read, const int16_t *hp,
+                                        const ObservationModelParameters &p, MLAlignment &ml)
+{
+    const int L = int(read.size()), Hs = int(hap.size());
+    ml.align = std::string(Hs, 'R');
+    ml.indels.clear(); ml.snps.clear(); ml.hapIndelCovered.clear(); ml.hapSNPCovered.clear();
+    ml.hpos.assign(L, 0);
+    ml.firstBase = -1; ml.lastBase = -1;
+    ml.nBQT = 0; ml.nmmBQT = 0; ml.mLogBQ = 0.0; ml.nMMRight = 0; ml.nMMLeft = 0; ml.numIndels = 0; ml.numMismatch = 0;
+    for (int b = 0; b < L; b++) ml.hpos[b] = hp[b];
+    int b = 0;
+    while (b < L) {
+        const int h = hp[b];
+        if (h == MLAlignment::INS) {
+            // inserted state numS+x: x-1 is the last haplotype base the read consumed before the run (an insertion
+            // is entered from "on base x", ObservationModelFB.cpp:1823-1826 / 1746-1749), so pos = x (:1380)
+            int rpos = b, len = 0;
+            while (b < L && hp[b] == MLAlignment::INS) { b++; len++; }
+            int pos;
+            if (rpos > 0 && hp[rpos - 1] >= 0) pos = hp[rpos - 1] + 1;
+            else if (b < L && hp[b] >= 0) pos = hp[b];           // run starts the read: next on-haplotype base
+            else pos = (rpos > 0 && hp[rpos - 1] == MLAlignment::LO) ? 1 : Hs;   // degenerate: only off-haplotype neighbours
+            std::string seq = read.seq.seq.substr(rpos, len);
+            ml.indels[pos] = AlignedVariant(std::string("+").append(seq), pos, pos, rpos, b - 1);
+            ml.numIndels++;
+            continue;
+        }
+        if (h >= 0) {
+            if (ml.firstBase == -1) ml.firstBase = h; else if (h < ml.firstBase) ml.firstBase = h;
+            if (ml.lastBase == -1) ml.lastBase = h; else if (h > ml.lastBase) ml.lastBase = h;
+            if (read.qual[b] > p.checkBaseQualThreshold) {
+                ml.nBQT++;
+                ml.mLogBQ += log10(1.0 - read.qual[b]);
+            }
+            if (read.seq[b] != hap.seq[h]) {
+                std::string snp;
+                snp += hap.seq[h];
+                snp.append("=>");
+                snp += read.seq[b];
+                if (read.qual[b] > p.checkBaseQualThreshold) ml.nmmBQT++;
+                if (b < 6) ml.nMMLeft++;
+                if (b > L - 6) ml.nMMRight++;
+                if (read.qual[b] > 0.95) ml.numMismatch++;
+                ml.snps[h] = AlignedVariant(snp, h, h, b, b);
+                ml.align[h] = read.seq[b];
+            }
+            if (b < L - 1) {
+                // next state on a base (or right of the haplotype) more than one position further: deletion (:1437-1453)
+                const int nh = hp[b + 1];
+                int ns = -1;                       // haplotype-state index (s = h+1); RO = Hs+1
+                if (nh >= 0) ns = nh + 1;
+                else if (nh == MLAlignment::RO) ns = Hs + 1;
+                else if (nh == MLAlignment::LO) ns = 0;
+                const int s = h + 1;
+                if (ns >= 0 && ns - s > 1) {
+                    const int pos = s;
+                    const int len = ns - s - 1;
+                    for (int y = pos; y < len + pos && y < Hs; y++) ml.align[y] = 'D';
+                    std::string seq = hap.seq.substr(pos, len);
+                    ml.indels[pos] = AlignedVariant(std::string("-").append(seq), pos, pos + len - 1, b, b + 1);
+                    ml.numIndels++;
+                }
+            }
+        }
+        b++;
+    }
+    for (std::map<int, AlignedVariant>::const_iterator it = hap.indels.begin(); it != hap.indels.end(); ++it)
+        ml.hapIndelCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
+    for (std::map<int, AlignedVariant>::const_iterator it = hap.snps.begin(); it != hap.snps.end(); ++it)
+        ml.hapSNPCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
+}
+
+void LikelihoodEngine::computeLikelihoods(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
+                                          std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos,
+                                          uint32_t rightPos, std::vector<int> &onHap)
+{
+    std::vector<WindowJob> jobs(1);
+    jobs[0].haps = &haps; jobs[0].reads = &reads; jobs[0].leftPos = leftPos; jobs[0].rightPos = rightPos;
+    jobs[0].liks = &liks; jobs[0].onHap = &onHap;
+    computeLikelihoodsBatch(jobs);
+    if (!jobs[0].error.empty()) throw jobs[0].error;
+}
+
+void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
+{
+    const int W = int(jobs.size());
+    // ---- pack (CSR) ----
+    std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, read_seq_off(1, 0);
+    std::vector<uint32_t> win_hap_start, read_start;
+    std::string hap_seq, read_seq;
+    std::vector<uint8_t> read_qidx, read_mqidx, read_flags;
+    std::map<double, int> qmap, mqmap;
+    std::vector<double> qtab, mqtab;
+    for (int w = 0; w < W; w++) {
+        WindowJob &J = jobs[w];
+        J.error.clear();
+        win_hap_start.push_back(J.leftPos);
+        for (size_t h = 0; h < J.haps->size(); h++) {
+            const Haplotype &H = (*J.haps)[h];
+            hap_seq += H.seq;
+            hap_seq_off.push_back(int32_t(hap_seq.size()));
+            for (std::map<int, AlignedVariant>::const_iterator it = H.indels.begin(); it != H.indels.end(); ++it) {
+                hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
+            }
+            for (std::map<int, AlignedVariant>::const_iterator it = H.snps.begin(); it != H.snps.end(); ++it) {
+                hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
+            }
+            hap_var_off.push_back(int32_t(hap_var.size() / 2));
+        }
+        win_hap_off.push_back(win_hap_off.back() + int32_t(J.haps->size()));
+        for (size_t r = 0; r < J.reads->size(); r++) {
+            const Read &R = (*J.reads)[r];
+            if (R.qual.size() != R.size()) throw std::string("Read: qual and seq differ in length");
+            read_seq += R.seq.seq;
+            read_seq_off.push_back(int32_t(read_seq.size()));
+            for (size_t b = 0; b < R.qual.size(); b++) {
+                std::map<double, int>::iterator it = qmap.find(R.qual[b]);
+                if (it == qmap.end()) { it = qmap.insert(std::make_pair(R.qual[b], int(qtab.size()))).first; qtab.push_back(R.qual[b]); }
+                if (it->second > 255) throw std::string("more than 256 distinct base qualities in one batch");
+                read_qidx.push_back(uint8_t(it->second));
+            }
+            std::map<double, int>::iterator it = mqmap.find(R.mapQual);
+            if (it == mqmap.end()) { it = mqmap.insert(std::make_pair(R.mapQual, int(mqtab.size()))).first; mqtab.push_back(R.mapQual); }
+            if (it->second > 255) throw std::string("more than 256 distinct mapping qualities in one batch");
+            read_mqidx.push_back(uint8_t(it->second));
+            read_start.push_back(uint32_t(R.posStat.first));      // uint32_t(read.posStat.first), ObservationModelFB.cpp:52
+            read_flags.push_back(R.isUnmapped() ? 1 : 0);
+        }
+        win_read_off.push_back(win_read_off.back() + int32_t(J.reads->size()));
+    }
+    dd_batch B;
+    memset(&B, 0, sizeof(B));
+    B.n_windows = W;
+    B.win_hap_off = win_hap_off.data(); B.win_read_off = win_read_off.data(); B.win_hap_start = win_hap_start.data();
+    B.hap_seq_off = hap_seq_off.data(); B.hap_seq = hap_seq.data(); B.hap_var_off = hap_var_off.data();
+    B.hap_var = hap_var.empty() ? NULL : hap_var.data();
+    B.read_seq_off = read_seq_off.data(); B.read_seq = read_seq.data(); B.read_qidx = read_qidx.data();
+    B.read_mqidx = read_mqidx.data(); B.read_start = read_start.data(); B.read_flags = read_flags.data();
+    B.n_qual = int(qtab.size()); B.qual_table = qtab.data(); B.n_mapq = int(mqtab.size()); B.mapq_table = mqtab.data();
+
+    dd_sizes sz;
+    if (dd_batch_sizes(&B, &sz) != DD_SUCCESS) throw std::string(dd_last_error());
+    std::vector<int64_t> pair_off(W + 1), hpos_off(W + 1), vc_off(W + 1);
+    dd_batch_offsets(&B, pair_off.data(), hpos_off.data(), vc_off.data());
+
+    std::vector<double> ll(sz.n_pairs), llOn(sz.n_pairs), llOff(sz.n_pairs), mLogBQ(sz.n_pairs);
+    std::vector<uint8_t> offHap(sz.n_pairs), offHapHMQ(sz.n_pairs), onHapV(sz.n_reads ? sz.n_reads : 1);
+    std::vector<int16_t> hpos(sz.hpos_len ? sz.hpos_len : 1);
+    std::vector<int32_t> status(sz.n_pairs);
+    dd_result Rz;
+    memset(&Rz, 0, sizeof(Rz));
+    Rz.ll = ll.data(); Rz.llOn = llOn.data(); Rz.llOff = llOff.data(); Rz.mLogBQ = mLogBQ.data();
+    Rz.offHap = offHap.data(); Rz.offHapHMQ = offHapHMQ.data(); Rz.hpos = hpos.data(); Rz.status = status.data();
+    Rz.onHap = onHapV.data();
+    const dd_params P = to_abi(params);
+    if (sz.n_pairs > 0) {
+        const int rc = dd_compute_likelihoods(&P, &B, &Rz, device_);
+        if (rc != DD_SUCCESS) throw std::string("dd_compute_likelihoods: ") + dd_last_error();
+    }
+
+    // ---- unpack into liks[hidx][r] / onHap, window by window, in order ----
+    for (int w = 0; w < W; w++) {
+        WindowJob &J = jobs[w];
+        const size_t H = J.haps->size(), Rn = J.reads->size();
+        *J.onHap = std::vector<int>(Rn, 0);                                              // DInDel.cpp:1710
+        *J.liks = std::vector<std::vector<MLAlignment> >(H, std::vector<MLAlignment>(Rn)); // DInDel.cpp:1714
+        const int r0 = win_read_off[w];
+        const int64_t SL = int64_t(read_seq_off[win_read_off[w + 1]]) - read_seq_off[r0];
+        for (size_t h = 0; h < H && J.error.empty(); h++) {
+            for (size_t r = 0; r < Rn; r++) {
+                const int64_t p = pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
+                if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47
+                MLAlignment &ml = (*J.liks)[h][r];
+                const int16_t *hp = hpos.data() + hpos_off[w] + int64_t(h) * SL + (read_seq_off[r0 + r] - read_seq_off[r0]);
+                rebuildAlignment((*J.haps)[h], (*J.reads)[r], hp, params, ml);
+                ml.ll = ll[p]; ml.llOn = llOn[p]; ml.llOff = llOff[p];
+                ml.offHap = offHap[p] != 0; ml.offHapHMQ = offHapHMQ[p] != 0;
+                ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
+                if (!ml.offHapHMQ) (*J.onHap)[r] = 1;                                     // DInDel.cpp:1720
+                if (status[p] == DD_PAIR_LLPOS) {                                         // DInDel.cpp:1722-1731
+                    if (throwOnPositive_) { J.error = "Likelihood>0"; break; }
+                    std::cout << "hidx: " << h << " r: " << r << std::endl;
+                    std::cerr << "Likelihood>0" << std::endl;
+                    exit(1);
+                }
+                if (status[p] == DD_PAIR_NAN) {                                           // DInDel.cpp:1732-1735
+                    std::cout << "NAN/Inf error" << std::endl;
+                    J.error = "Nan detected";
+                    break;
+                }
+            }
+        }
+    }
+}
+
+} // namespace dindel

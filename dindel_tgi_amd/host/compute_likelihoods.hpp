@@ -1,0 +1,60 @@
+// compute_likelihoods.hpp — C++ host adapter with the reference's operator interface for the hot path.
+//
+//   void DetInDel::computeLikelihoods(const vector<Haplotype>&, const vector<Read>&,
+//                                     vector<vector<MLAlignment> >& liks, uint32_t leftPos, uint32_t rightPos,
+//                                     vector<int>& onHap);                 reference DInDel.hpp:136, DInDel.cpp:1707-1739
+//
+// Same argument meaning, same outputs (liks[hidx][r], onHap[r]) and the same error behaviour:
+//   * haplotype shorter than maxLengthDel  -> throws std::string("hapSize error.")   (ObservationModelFB.cpp:47)
+//   * NaN / Inf log-likelihood             -> throws std::string("Nan detected")     (DInDel.cpp:1732-1735)
+//   * log-likelihood > 0.1                 -> "Likelihood>0" on stderr, exit(1)      (DInDel.cpp:1722-1731)
+//                                             (setThrowOnPositiveLikelihood(true) turns the exit into a throw)
+// All arithmetic runs on the GPU through the C ABI (include/dindel_hmm.h); this class only packs the
+// windows, calls dd_compute_likelihoods and rebuilds the MLAlignment records (variant strings from hpos).
+#ifndef DINDEL_COMPUTE_LIKELIHOODS_HPP
+#define DINDEL_COMPUTE_LIKELIHOODS_HPP
+#include <cstdint>
+#include <vector>
+#include "dindel_types.hpp"
+
+namespace dindel {
+
+struct WindowJob {                      // one call of the reference's computeLikelihoods
+    const std::vector<Haplotype> *haps;
+    const std::vector<Read> *reads;
+    uint32_t leftPos, rightPos;
+    std::vector<std::vector<MLAlignment> > *liks;   // OUT
+    std::vector<int> *onHap;                        // OUT
+    std::string error;                              // OUT: empty, or the string the reference would have thrown
+};
+
+class LikelihoodEngine {
+public:
+    explicit LikelihoodEngine(const ObservationModelParameters &obsParams, int device = 0)
+        : params(obsParams), device_(device), throwOnPositive_(false) {}
+
+    ObservationModelParameters params;   // the reference passes this->params.obsParams implicitly (DInDel.cpp:1718)
+
+    // drop-in for one window
+    void computeLikelihoods(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
+                            std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos, uint32_t rightPos,
+                            std::vector<int> &onHap);
+
+    // the batched form a GPU wants: prepare-N -> one launch -> reduce-N in order.  A window that would have
+    // thrown gets its message in WindowJob::error (the caller turns it into the "skipped" row, DInDel.cpp:1361-1408).
+    void computeLikelihoodsBatch(std::vector<WindowJob> &jobs);
+
+    void setThrowOnPositiveLikelihood(bool v) { throwOnPositive_ = v; }
+
+    // ObservationModelFBMax::reportVariants (ObservationModelFB.cpp:1351-1475) from the device's hpos: fills
+    // hpos, indels, snps, align, firstBase/lastBase, counters and the covered maps.  Exposed for tests.
+    static void rebuildAlignment(const Haplotype &hap, const Read &read, const int16_t *hpos,
+                                 const ObservationModelParameters &p, MLAlignment &ml);
+
+private:
+    int device_;
+    bool throwOnPositive_;
+};
+
+} // namespace dindel
+#endif

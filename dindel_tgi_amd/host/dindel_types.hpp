@@ -1,0 +1,127 @@
+// dindel_types.hpp — host-side value types of the likelihood path (C++ mirror of the reference interface).
+//
+// Only the fields the path reads or writes are modelled; names follow the reference so
+// that call sites read the same:
+//   Haplotype   reference Haplotype.hpp:40-312   (seq, indels, snps)
+//   Read        reference Read.hpp:31-449        (seq, qual, mapQual, posStat, isUnmapped())
+//   AlignedVariant reference Variant.hpp:78-175  (string form, start/end in haplotype and read, isCovered)
+//   MLAlignment reference MLAlignment.hpp:28-76  (the per-(read,haplotype) result record)
+//   ObservationModelParameters reference ObservationModel.hpp:28-99
+// Written from scratch for this library; no libbam / Boost dependency.
+#ifndef DINDEL_TYPES_HPP
+#define DINDEL_TYPES_HPP
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace dindel {
+
+class AlignedVariant {
+public:
+    enum Type { INS, DEL, SNP, REF };
+    AlignedVariant() : type(REF), length(0), startHap(-1), endHap(-1), startRead(-1), endRead(-1) {}
+    // "+SEQ" insertion, "-SEQ" deletion, "X=>Y" SNP — reference Variant.hpp:43-74
+    AlignedVariant(const std::string &s, int _startHap, int _endHap, int _startRead, int _endRead)
+        : str(s), startHap(_startHap), endHap(_endHap), startRead(_startRead), endRead(_endRead)
+    {
+        if (s.size() > 1 && s[0] == '-') { type = DEL; length = int(s.size()) - 1; seq = s.substr(1); }
+        else if (s.size() > 1 && s[0] == '+') { type = INS; length = int(s.size()) - 1; seq = s.substr(1); }
+        else if (s.size() == 4 && s[1] == '=' && s[2] == '>') { type = SNP; length = 1; seq = s; }
+        else throw std::string("Unrecognized variant");
+    }
+    const std::string &getString() const { return str; }
+    const std::string &getSeq() const { return seq; }
+    Type getType() const { return type; }
+    int size() const { return length; }
+    bool isIndel() const { return type == INS || type == DEL; }
+    bool isSNP() const { return type == SNP; }
+    int getStartHap() const { return startHap; }
+    int getEndHap() const { return endHap; }
+    int getStartRead() const { return startRead; }
+    int getEndRead() const { return endRead; }
+    // reference Variant.hpp:125-128
+    bool isCovered(int pad, int firstBase, int lastBase) const
+    {
+        return firstBase + pad <= startRead && lastBase - pad >= endRead;
+    }
+private:
+    Type type;
+    std::string seq, str;
+    int length;
+    int startHap, endHap;     // position of the variant in the haplotype the read is aligned to
+    int startRead, endRead;   // position of the variant in the read aligned to the haplotype
+};
+
+class MLAlignment {
+public:
+    static const int INS = -1, DEL = -2, LO = -3, RO = -4;   // reference MLAlignment.hpp:31-34
+    MLAlignment()
+        : relPos(-1), firstBase(-1), lastBase(-1), ll(0.0), llOn(0.0), llOff(0.0), offHap(false), offHapHMQ(false),
+          hl(-1), hr(-1), numIndels(0), numMismatch(0), nBQT(0), nmmBQT(0), mLogBQ(0.0), nMMLeft(0), nMMRight(0) {}
+    int relPos;
+    int firstBase, lastBase;
+    std::map<int, AlignedVariant> indels, snps;
+    std::map<int, bool> hapIndelCovered, hapSNPCovered;
+    double ll, llOn, llOff;
+    bool offHap, offHapHMQ;
+    int hl, hr;
+    int numIndels, numMismatch;
+    int nBQT, nmmBQT;
+    double mLogBQ;
+    int nMMLeft, nMMRight;
+    std::string align;
+    std::vector<int> hpos;
+    operator double() const { return ll; }
+};
+
+class Haplotype {
+public:
+    Haplotype() {}
+    explicit Haplotype(const std::string &s) : seq(s) {}
+    std::string seq;
+    std::map<int, AlignedVariant> indels, snps;   // variants of this haplotype w.r.t. the reference sequence
+    size_t size() const { return seq.size(); }
+    const char &operator[](size_t i) const { return seq[i]; }
+};
+
+class Read {
+public:
+    Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false) {}
+    Haplotype seq;                       // read.seq.seq is the base string, as in the reference
+    std::vector<double> qual;            // P(base correct) — reference Read.hpp:143-148
+    double mapQual;                      // P(mapping correct) — reference Read.hpp:127-131
+    std::pair<double, double> posStat;   // .first: mean first-base position — reference Read.hpp:261-306
+    uint32_t pos;
+    bool unmapped;                       // BAM flag 0x4 (the reference reads bam->core.flag, Read.hpp:200)
+    size_t size() const { return seq.size(); }
+    bool isUnmapped() const { return unmapped; }
+    void setAllQual(double v) { qual.assign(seq.size(), v); }
+    // Phred -> probability exactly as the BAM constructor does — reference Read.hpp:127-131, 143-148
+    static double phredToProb(double phred);
+};
+
+// reference ObservationModel.hpp:28-99 (fields the path reads)
+class ObservationModelParameters {
+public:
+    ObservationModelParameters() { setDefaultValues(); }
+    void setDefaultValues()
+    {
+        pError = 1e-4; pMut = 1e-4; maxLengthIndel = 10; maxLengthDel = maxLengthIndel; mapQualThreshold = 100.0;
+        pFirstgLO = 0.01; checkBaseQualThreshold = 0.95; bMid = -1; forceReadOnHaplotype = false;
+        mapUnmappedReads = false; padCover = 5; maxMismatch = 1;
+    }
+    // what main() installs from the CLI defaults — reference DInDel.cpp:3937-3949, 4122-4157
+    void setCLIDefaultValues()
+    {
+        setDefaultValues();
+        pError = 5e-4; pMut = 1e-5; maxLengthIndel = 5; maxLengthDel = 5; padCover = 2; maxMismatch = 2;
+    }
+    double pError, pMut, mapQualThreshold, pFirstgLO, checkBaseQualThreshold;
+    int maxLengthIndel, maxLengthDel, bMid, padCover, maxMismatch;
+    bool forceReadOnHaplotype, mapUnmappedReads;
+};
+
+} // namespace dindel
+#endif

@@ -1,0 +1,121 @@
+// host_capi.cpp — small extern "C" hooks so the pytest suite can drive the C++ host adapter
+// (LikelihoodEngine) through ctypes.  Not part of the drop-in boundary.
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include "compute_likelihoods.hpp"
+
+using namespace dindel;
+
+static void json_ml(std::ostringstream &os, const MLAlignment &ml)
+{
+    os.precision(17);
+    os << "{\"ll\":" << ml.ll << ",\"llOn\":" << ml.llOn << ",\"llOff\":" << ml.llOff << ",\"mLogBQ\":" << ml.mLogBQ
+       << ",\"offHap\":" << int(ml.offHap) << ",\"offHapHMQ\":" << int(ml.offHapHMQ) << ",\"numIndels\":" << ml.numIndels
+       << ",\"numMismatch\":" << ml.numMismatch << ",\"nBQT\":" << ml.nBQT << ",\"nmmBQT\":" << ml.nmmBQT
+       << ",\"nMMLeft\":" << ml.nMMLeft << ",\"nMMRight\":" << ml.nMMRight << ",\"firstBase\":" << ml.firstBase
+       << ",\"lastBase\":" << ml.lastBase << ",\"align\":\"" << ml.align << "\",\"hpos\":[";
+    for (size_t i = 0; i < ml.hpos.size(); i++) os << (i ? "," : "") << ml.hpos[i];
+    os << "],\"indels\":[";
+    bool first = true;
+    for (std::map<int, AlignedVariant>::const_iterator it = ml.indels.begin(); it != ml.indels.end(); ++it, first = false)
+        os << (first ? "" : ",") << "[" << it->first << ",\"" << it->second.getString() << "\"," << it->second.getStartHap() << ","
+           << it->second.getEndHap() << "," << it->second.getStartRead() << "," << it->second.getEndRead() << "]";
+    os << "],\"snps\":[";
+    first = true;
+    for (std::map<int, AlignedVariant>::const_iterator it = ml.snps.begin(); it != ml.snps.end(); ++it, first = false)
+        os << (first ? "" : ",") << "[" << it->first << ",\"" << it->second.getString() << "\"]";
+    os << "],\"hapIndelCovered\":[";
+    first = true;
+    for (std::map<int, bool>::const_iterator it = ml.hapIndelCovered.begin(); it != ml.hapIndelCovered.end(); ++it, first = false)
+        os << (first ? "" : ",") << "[" << it->first << "," << int(it->second) << "]";
+    os << "]}";
+}
+
+static ObservationModelParameters make_params(const double *pd, const int *pi)
+{
+    ObservationModelParameters p;
+    p.pError = pd[0]; p.pMut = pd[1]; p.pFirstgLO = pd[2]; p.mapQualThreshold = pd[3]; p.checkBaseQualThreshold = pd[4];
+    p.maxLengthDel = p.maxLengthIndel = pi[0]; p.padCover = pi[1]; p.bMid = pi[2];
+    return p;
+}
+
+static int emit(const std::string &s, char *out, int cap)
+{
+    if (int(s.size()) + 1 > cap) return -int(s.size()) - 1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return int(s.size());
+}
+
+extern "C" {
+
+// CPU only: reportVariants rebuilt from an hpos vector (no device involved)
+int ddh_rebuild_json(const char *hap, const char *read, const double *qual, const short *hpos, int L,
+                     const double *pd, const int *pi, const int *hap_indels /* n x {key,startRead,endRead} */, int n_hap_indels,
+                     char *out, int cap)
+{
+    try {
+        Haplotype H((std::string(hap)));
+        for (int i = 0; i < n_hap_indels; i++)
+            H.indels[hap_indels[3 * i]] = AlignedVariant("-A", hap_indels[3 * i], hap_indels[3 * i], hap_indels[3 * i + 1], hap_indels[3 * i + 2]);
+        Read R;
+        R.seq.seq = read;
+        R.qual.assign(qual, qual + L);
+        MLAlignment ml;
+        LikelihoodEngine::rebuildAlignment(H, R, hpos, make_params(pd, pi), ml);
+        std::ostringstream os;
+        json_ml(os, ml);
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// GPU: one window through LikelihoodEngine::computeLikelihoods.  haps / reads are '\n'-joined strings,
+// quals one double per read base (concatenated), mapq / start / unmapped per read.
+int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
+                            const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
+                            int device, char *out, int cap)
+{
+    try {
+        std::vector<Haplotype> haps;
+        std::vector<Read> reads;
+        std::istringstream hs(haps_nl), rs(reads_nl);
+        std::string line;
+        while (std::getline(hs, line)) if (!line.empty()) haps.push_back(Haplotype(line));
+        size_t qoff = 0, ri = 0;
+        while (std::getline(rs, line)) {
+            if (line.empty()) continue;
+            Read R;
+            R.seq.seq = line;
+            R.qual.assign(quals + qoff, quals + qoff + line.size());
+            qoff += line.size();
+            R.mapQual = mapq[ri];
+            R.posStat.first = pos_first[ri];
+            R.unmapped = unmapped[ri] != 0;
+            reads.push_back(R);
+            ri++;
+        }
+        LikelihoodEngine eng(make_params(pd, pi), device);
+        eng.setThrowOnPositiveLikelihood(true);
+        std::vector<std::vector<MLAlignment> > liks;
+        std::vector<int> onHap;
+        eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        std::ostringstream os;
+        os << "{\"onHap\":[";
+        for (size_t i = 0; i < onHap.size(); i++) os << (i ? "," : "") << onHap[i];
+        os << "],\"liks\":[";
+        for (size_t h = 0; h < liks.size(); h++) {
+            os << (h ? "," : "") << "[";
+            for (size_t r = 0; r < liks[h].size(); r++) { if (r) os << ","; json_ml(os, liks[h][r]); }
+            os << "]";
+        }
+        os << "]}";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+} // extern "C"
