@@ -42,6 +42,23 @@ def algorithmic_bytes_per_pair(L, Hs, R):
     return 4.0 * L + 48.0 + float(Hs) / R
 
 
+def measured_traffic(n_pairs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, profiles/r*/..._pmc.json) — only when the profiled launch had
+    exactly this many pairs; otherwise None.  bench.py itself cannot collect PMC counters."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for cfg in d.values():
+            if isinstance(cfg, dict) and cfg.get("pairs_per_launch") == n_pairs and "hbm_bytes_raw" in cfg:
+                best = dict(bytes=cfg["hbm_bytes_raw"], source=os.path.relpath(f, ROOT))
+    return best
+
+
 def cpu_baseline(pb, params, seconds_target=15.0):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
     from tests import _oracle
@@ -162,7 +179,10 @@ def main():
             "windows_per_s": total_windows / elapsed,
             "pairs_per_s": n_pairs * world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": (measured_traffic(n_pairs) or {}).get("bytes"),
+                         "traffic_source": (measured_traffic(n_pairs) or {}).get("source"),
+                         "algorithmic_bytes_per_launch": bpp * n_pairs,
                          "kernel": capi.load().dd_kernel_name().decode(), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_pair": bpp,
                          "note": "scalar max-plus fp64 recurrence: bound by fp64 VALU/LDS, not HBM (SURVEY §8d); "
