@@ -1,0 +1,170 @@
+"""GPU parity on the edge cases of the path (bit-equal to the oracle, through the C ABI):
+empty / ragged windows, extreme sizes, N bases, homopolymers, repeats with exact ties, bMid corner cases,
+non-overlapping and unmapped reads, quality extremes, the hapSize error status."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dindel_tgi_amd import capi
+from dindel_tgi_amd.batch import ReadRec, Window, alloc_result, pack, phred_to_prob
+from tests import _oracle
+from tests.test_gpu_parity import assert_same, run_host_api
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(12345)
+
+
+def rnd(n, alphabet="ACGT"):
+    return "".join(RNG.choice(list(alphabet), n))
+
+
+def mutate(s, rate=0.02):
+    out = list(s)
+    for i in range(len(out)):
+        if RNG.random() < rate:
+            out[i] = RNG.choice(list("ACGT"))
+    return "".join(out)
+
+
+def reads_from(hap, n, L, start0=1000, q=0.999, mq=0.9999, junk=0.1):
+    reads = []
+    for _ in range(n):
+        Lr = int(L)
+        off = int(RNG.integers(-Lr // 2, max(1, len(hap) - Lr // 2)))
+        seq = "".join(hap[i] if 0 <= i < len(hap) else RNG.choice(list("ACGT")) for i in range(off, off + Lr))
+        if RNG.random() < junk:
+            seq = rnd(Lr)
+        reads.append(ReadRec(mutate(seq), [q] * Lr, mq, start0 + off))
+    return reads
+
+
+def check(lib, windows, params=None):
+    p = params or capi.params_cli_defaults()
+    pb = pack(windows)
+    got = run_host_api(lib, p, pb)
+    want = _oracle.batch(p, pb, nthreads=8)
+    assert_same(got, want, pb)
+    return pb, got
+
+
+def test_ragged_and_empty_windows(lib):
+    h1, h2 = rnd(90), rnd(131)
+    ws = [Window(1000, [h1, h1[:40] + h1[43:]], reads_from(h1, 7, 50)),
+          Window(5000, [h2], []),                                   # window without reads
+          Window(7000, [], reads_from(h2, 3, 30)),                  # window without haplotypes
+          Window(9000, [h2, h2[:60] + "TT" + h2[60:], h2[:70] + h2[71:]],
+                 [ReadRec(h2[10:11], [0.99], 0.99, 9010),           # L = 1
+                  ReadRec(h2[10:12], [0.99, 0.9], 0.99, 9010),      # L = 2
+                  ReadRec(h2[5:125], [0.999] * 120, 0.9999, 9005)])]
+    pb, got = check(lib, ws)
+    assert pb.n_pairs == 2 * 7 + 0 + 0 + 3 * 3
+    assert got["onHap"][7:10].tolist() == [0, 0, 0]                 # reads of the hap-less window
+
+
+def test_n_bases_and_iupac_in_reads(lib):
+    hap = rnd(100)
+    hapN = hap[:50] + "NNN" + hap[53:]                              # --changeINStoN style haplotype
+    reads = reads_from(hap, 12, 60)
+    reads.append(ReadRec(hap[20:45] + "N" + hap[46:80], [0.999] * 60, 0.9999, 1020))
+    reads.append(ReadRec(hap[20:45] + "R" + hap[46:60] + "nY" + hap[62:80], [0.99] * 60, 0.999, 1020))
+    reads.append(ReadRec("N" * 40, [0.9] * 40, 0.99, 1030))
+    check(lib, [Window(1000, [hap, hapN], reads)])
+
+
+def test_homopolymers_incl_last_base_quirk(lib):
+    haps = []
+    for run in (1, 2, 3, 5, 9, 10, 11, 15, 30, 60):
+        left, right = rnd(35), rnd(30)
+        haps.append(left + "A" * run + right)                       # run in the middle
+        haps.append(left + rnd(20) + "T" * run)                     # run ending at the last base: E[hapSize-1] (:1702)
+    ws = []
+    for i in range(0, len(haps), 4):
+        hs = haps[i:i + 4]
+        rs = []
+        for h in hs:
+            rs += reads_from(h, 4, 45)
+            mid = len(h) // 2
+            rs.append(ReadRec(h[mid - 20:mid] + h[mid + 1:mid + 21], [0.999] * 40, 0.9999, 1000 + mid - 20))   # 1-bp deletion
+        ws.append(Window(1000, hs, rs))
+    check(lib, ws)
+
+
+def test_repeats_exact_ties(lib):
+    """Tandem repeats: many alignments tie exactly; pins updateMax's tie-break and the near-tie join replay."""
+    ws = []
+    for unit in ("AC", "CAG", "T", "AAG", "ACGT"):
+        hap = rnd(15) + unit * (60 // len(unit)) + rnd(15)
+        rep = unit * 40
+        reads = [ReadRec(rep[:k], [0.999] * k, 0.9999, 1015) for k in (12, 24, 30)]
+        reads += [ReadRec(unit * 40, [0.99] * len(unit * 40), 0.99, 1000)]                 # longer than the repeat
+        reads += reads_from(hap, 6, 40)
+        ws.append(Window(1000, [hap, hap[:20] + hap[20 + len(unit):], rnd(len(hap))], reads))
+    ws.append(Window(1000, ["A" * 80], [ReadRec("A" * 30, [0.999] * 30, 0.9999, 1010), ReadRec("A" * 90, [0.99] * 90, 0.9, 990)]))
+    for p in (capi.params_cli_defaults(), capi.params_struct_defaults()):
+        check(lib, ws, p)
+
+
+def test_bmid_corner_cases(lib):
+    hap = rnd(120)
+    reads = [ReadRec(hap[0:50], [0.999] * 50, 0.9999, 1000 - 49),       # overlaps only its last base
+             ReadRec(hap[70:120], [0.999] * 50, 0.9999, 1000 + 120),    # starts exactly at hapEnd
+             ReadRec(hap[70:120], [0.999] * 50, 0.9999, 1000 + 121),    # beyond hapEnd -> L/2
+             ReadRec(hap[0:50], [0.999] * 50, 0.9999, 1000 - 50),       # ends before hapStart -> L/2
+             ReadRec(hap[30:80], [0.999] * 50, 0.9999, 0xFFFFFFFF),     # uint32(-1.0) start
+             ReadRec(hap[30:80], [0.999] * 50, 0.9999, 3),              # far left of the window
+             ReadRec(hap[30:80], [0.999] * 50, 0.9999, 1030, unmapped=True)]
+    ws = [Window(1000, [hap, hap[:60] + hap[62:]], reads), Window(10, [hap], reads[:3]), Window(0xFFFFFF00, [hap], reads)]
+    check(lib, ws)
+    for bmid in (0, 10, 49, 500):
+        p = capi.params_cli_defaults()
+        p.bMid = bmid
+        check(lib, ws[:1], p)
+
+
+def test_quality_extremes_and_full_tables(lib):
+    hap = rnd(110)
+    quals = np.concatenate([phred_to_prob(np.arange(0, 94)), [1e-16, 0.5, 0.25, 0.95, 0.950000001, 0.949999999]])
+    mqs = [1e-16, 0.5, 0.9, 0.99, 1 - 1e-10, 1 - 1e-11, 1 - 1e-16]
+    reads = []
+    for i in range(40):
+        L = 50
+        off = int(RNG.integers(0, 60))
+        q = RNG.choice(quals, L)
+        reads.append(ReadRec(mutate(hap[off:off + L], 0.05), q, mqs[i % len(mqs)], 1000 + off))
+    check(lib, [Window(1000, [hap, hap[:55] + "GGG" + hap[55:]], reads)])
+    # 256 distinct base qualities in one batch
+    q256 = np.linspace(0.3, 0.99999, 256)
+    reads = [ReadRec(hap[10:74], q256[64 * i:64 * i + 64], 0.999, 1010) for i in range(4)]
+    check(lib, [Window(1000, [hap], reads)])
+
+
+def test_hapsize_error_status_in_mixed_batch(lib):
+    p = capi.params_cli_defaults()                                  # maxLengthDel = 5
+    hap = rnd(80)
+    ws = [Window(1000, [hap, "ACGT"], reads_from(hap, 5, 30)),      # second haplotype shorter than maxLengthDel
+          Window(2000, ["ACGTA", hap], reads_from(hap, 4, 30, start0=2000))]   # hapSize == maxLengthDel is allowed
+    pb, got = check(lib, ws, p)
+    st = got["status"][:pb.n_pairs]
+    assert st[:5].tolist() == [0] * 5 and st[5:10].tolist() == [capi.DD_PAIR_HAPSIZE] * 5
+    assert (st[10:] == 0).all()
+
+
+@pytest.mark.parametrize("hs,L,n", [(62, 36, 6), (63, 100, 4), (126, 100, 4), (127, 100, 3), (200, 150, 3), (300, 100, 2),
+                                     (400, 101, 2), (700, 120, 1), (766, 64, 1)])
+def test_all_lane_tilings(lib, hs, L, n):
+    """Haplotype lengths on both sides of every K boundary (K = 1,2,3,4,6,8,12), up to the 766-bp limit."""
+    hap = rnd(hs)
+    var = hap[:hs // 2] + hap[hs // 2 + 2:]
+    check(lib, [Window(1000, [hap, var], reads_from(hap, n, L) + reads_from(var, n, L))])
+    p = capi.params_struct_defaults()                               # D = 11
+    check(lib, [Window(1000, [hap], reads_from(hap, n, min(L, 100)))], p)
+
+
+def test_shapes_beyond_lds_are_refused_not_miscomputed(lib):
+    hap = rnd(766)
+    pb = pack([Window(1000, [hap], reads_from(hap, 1, 1000))])
+    arrs, res = alloc_result(pb)
+    b = pb.ctypes_batch()
+    p = capi.params_cli_defaults()
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED

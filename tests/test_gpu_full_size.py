@@ -1,0 +1,111 @@
+"""BASELINE.json configs[1] at full size (10,000 windows x 8 haplotypes x 200 reads = 1.6e7 pairs) on the GPU.
+The oracle needs ~1 h for this, so parity is checked through size-independent properties plus an oracle
+comparison of randomly chosen windows."""
+import numpy as np
+import pytest
+import torch
+
+from dindel_tgi_amd import capi, synth
+from dindel_tgi_amd.device import DeviceBatch
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+N_WIN = 10000
+
+
+@pytest.fixture(scope="module")
+def full():
+    pb = synth.generate(N_WIN, H=8, R=200, L=100, hap_len=120, seed=0xC0FFEE)
+    p = capi.params_cli_defaults()
+    dev = DeviceBatch(pb, p, "cuda:0")
+    dev.launch()
+    torch.cuda.synchronize()
+    return pb, p, dev
+
+
+def checksum(t):
+    """order-sensitive 64-bit checksum of a tensor's bytes (a checksum of checksums over 1 MiB chunks)."""
+    b = t.contiguous().view(torch.uint8)
+    n = b.numel() // 8 * 8
+    w = b[:n].view(torch.int64)
+    idx = torch.arange(w.numel(), device=w.device, dtype=torch.int64)
+    return int(((w * (2 * idx + 1)).sum() + b[n:].to(torch.int64).sum()).item())
+
+
+def test_every_pair_ok_and_bounded(full):
+    pb, p, dev = full
+    n = pb.n_pairs
+    assert int((dev.out["status"][:n] != 0).sum()) == 0
+    ll = dev.out["ll"][:n]
+    assert bool(torch.isfinite(ll).all()) and float(ll.max()) <= 0.1          # DInDel.cpp:1722
+    assert bool((dev.out["llOn"][:n] <= ll + 1e-9).logical_or(dev.out["llOff"][:n] <= ll + 1e-9).all())
+    # ll is the max over all states: it equals max(llOn, llOff, the two RO states) -> never below llOn/llOff
+    assert bool((ll >= torch.maximum(dev.out["llOn"][:n], dev.out["llOff"][:n]) - 1e-10).all())
+
+
+def test_traceback_is_a_monotone_path(full):
+    """hpos of every pair: on-haplotype positions strictly increase along the read; LO only before, RO only after."""
+    pb, p, dev = full
+    hp = dev.out["hpos"][:pb.hpos_len].view(-1, 100).to(torch.int32)          # all reads are 100 bp here
+    on = hp >= 0
+    big = torch.where(on, hp, torch.full_like(hp, -1))
+    run_max = torch.cummax(big, dim=1).values
+    prev = torch.cat([torch.full_like(run_max[:, :1], -1), run_max[:, :-1]], dim=1)
+    assert bool((~on | (hp > prev)).all())                                     # strictly increasing
+    seen_on = torch.cumsum(on.to(torch.int32), dim=1) > 0
+    assert bool((~(hp == -3) | ~seen_on).all())                                # LO never after an on-haplotype base
+    first = torch.where(on, hp, torch.full_like(hp, 1 << 20)).min(dim=1).values
+    last = big.max(dim=1).values
+    fb = dev.out["firstBase"][:pb.n_pairs].to(torch.int32)
+    lb = dev.out["lastBase"][:pb.n_pairs].to(torch.int32)
+    none = ~on.any(dim=1)
+    assert bool(((fb == first) | none).all()) and bool(((lb == last) | none).all())
+    assert bool((fb[none] == -1).all())
+    # numIndels = insertion runs + deletions, recomputed from hpos alone
+    ins = hp == -1
+    prev_ins = torch.cat([torch.zeros_like(ins[:, :1]), ins[:, :-1]], dim=1)
+    n_ins = (ins & ~prev_ins).sum(dim=1)
+    nxt = torch.cat([hp[:, 1:], torch.full_like(hp[:, :1], -1)], dim=1)
+    hs = torch.from_numpy(np.repeat(np.diff(pb.a["hap_seq_off"]).astype(np.int32), 200)).to(hp.device)
+    nxt_state = torch.where(nxt >= 0, nxt, torch.where(nxt == -4, hs[:, None], torch.full_like(nxt, -(1 << 20))))
+    last_col = torch.arange(100, device=hp.device)[None, :] == 99
+    n_del = (on & ~last_col & (nxt_state - hp > 1)).sum(dim=1)
+    assert bool(((n_ins + n_del).to(torch.int16) == dev.out["numIndels"][:pb.n_pairs]).all())
+
+
+def test_idempotent_and_shard_invariant(full):
+    pb, p, dev = full
+    keys = ["ll", "llOn", "llOff", "mLogBQ", "offHap", "offHapHMQ", "numIndels", "numMismatch", "nBQT", "nmmBQT",
+            "nMMLeft", "nMMRight", "firstBase", "lastBase", "hpos", "var_covered", "status", "onHap"]
+    before = {k: checksum(dev.out[k]) for k in keys}
+    dev.launch()
+    torch.cuda.synchronize()
+    assert before == {k: checksum(dev.out[k]) for k in keys}                   # second launch: identical bytes
+    # two contiguous shards (how ranks split a job) reproduce the single-batch result
+    half = N_WIN // 2
+    for (w0, w1) in ((0, half), (half, N_WIN)):
+        sh = pb.slice_windows(w0, w1)
+        d2 = DeviceBatch(sh, p, "cuda:0")
+        d2.launch()
+        torch.cuda.synchronize()
+        p0, p1 = int(pb.win_pair_off[w0]), int(pb.win_pair_off[w1])
+        h0, h1 = int(pb.win_hpos_off[w0]), int(pb.win_hpos_off[w1])
+        assert torch.equal(d2.out["ll"][:sh.n_pairs], dev.out["ll"][p0:p1])
+        assert torch.equal(d2.out["hpos"][:sh.hpos_len], dev.out["hpos"][h0:h1])
+        assert torch.equal(d2.out["offHapHMQ"][:sh.n_pairs], dev.out["offHapHMQ"][p0:p1])
+        del d2
+
+
+def test_random_windows_against_oracle(full):
+    pb, p, dev = full
+    rng = np.random.default_rng(1)
+    got = None
+    for w in rng.choice(N_WIN, 6, replace=False):
+        sh = pb.slice_windows(int(w), int(w) + 1)
+        want = _oracle.batch(p, sh, nthreads=8)
+        p0, p1 = int(pb.win_pair_off[w]), int(pb.win_pair_off[w + 1])
+        h0, h1 = int(pb.win_hpos_off[w]), int(pb.win_hpos_off[w + 1])
+        for k in ("ll", "llOn", "llOff", "mLogBQ", "offHap", "offHapHMQ", "numIndels", "numMismatch", "nBQT", "nmmBQT",
+                  "nMMLeft", "nMMRight", "firstBase", "lastBase"):
+            assert np.array_equal(dev.out[k][p0:p1].cpu().numpy(), want[k][:sh.n_pairs]), (k, w)
+        assert np.array_equal(dev.out["hpos"][h0:h1].cpu().numpy(), want["hpos"][:sh.hpos_len])
