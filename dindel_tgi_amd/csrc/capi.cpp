@@ -120,6 +120,8 @@ struct DevBuf {
 
 } // namespace
 
+static int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
 extern "C" void dd_debug_set_stamp_buffer(void *p) { g_dbg = static_cast<unsigned long long *>(p); }
@@ -130,6 +132,11 @@ extern "C" {
 int dd_abi_version(void) { return DD_ABI_VERSION; }
 const char *dd_last_error(void) { return g_err.c_str(); }
 const char *dd_kernel_name(void) { return "dd_hmm_kernel"; }
+
+void dd_last_launch(int32_t out[8])
+{   // K, D build, waves per workgroup, LDS bytes per workgroup, grid, read split, LDS per wave, shared LDS
+    for (int i = 0; i < 8; i++) out[i] = g_last_launch[i];
+}
 
 int dd_device_count(void)
 {
@@ -299,15 +306,26 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     A.dbg = g_dbg;
 #endif
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
-    // 4 waves per workgroup when the back-pointer tiles fit; fewer for long reads x long haplotypes
-    int waves = DD_WAVES;
-    size_t lds = lds_layout(K, Dt, b->max_read_len, b->n_qual, waves, A);
-    while (lds > 160u * 1024u && waves > 1) {
-        waves >>= 1;
+    // Waves per workgroup: whatever puts the most wavefronts on a CU given its 160 KiB of LDS (the
+    // back-pointer tile grows with read length x haplotype length); ties go to the larger workgroup,
+    // which amortises the per-haplotype setup over more reads.
+    int waves = 0;
+    size_t lds = 0;
+    {
+        int best_total = 0;
+        for (int wv = DD_WAVES; wv >= 1; wv--) {
+            ddk::KernelArgs tmp = A;
+            const size_t l = lds_layout(K, Dt, b->max_read_len, b->n_qual, wv, tmp);
+            if (l > 160u * 1024u) continue;
+            int blocks = (int)((160u * 1024u) / l);
+            int total = blocks * wv;
+            if (total > 32) total = 32;
+            if (total > best_total) { best_total = total; waves = wv; lds = l; }
+        }
+        if (waves == 0)
+            return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length needs more than 160 KiB of LDS per wavefront");
         lds = lds_layout(K, Dt, b->max_read_len, b->n_qual, waves, A);
     }
-    if (lds > 160u * 1024u)
-        return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length needs more than 160 KiB of LDS per wavefront");
     // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
     const int64_t target_blocks = 4096;
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
@@ -319,6 +337,9 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     A.n_split = (int32_t)split;
     const int64_t grid = (int64_t)b->n_haps * split;
     if (grid > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    g_last_launch[0] = K; g_last_launch[1] = Dt; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
+    g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
+    g_last_launch[7] = (int32_t)A.lds_shared_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(ddk::launch_hmm(K, Dt, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ) HIP_TRY(ddk::launch_onhap(A, st));

@@ -186,6 +186,9 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
 
 /* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
 const char *dd_kernel_name(void);
+/* geometry of the last dd_launch_device on this host thread's library instance:
+ * {K positions/lane, D build, waves/workgroup, LDS bytes/workgroup, grid, read split, LDS bytes/wave, shared LDS bytes} */
+void dd_last_launch(int32_t out[8]);
 const char *dd_last_error(void);
 int dd_abi_version(void);
 int dd_device_count(void);
