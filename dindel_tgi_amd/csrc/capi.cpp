@@ -56,7 +56,7 @@ int pick_Dt(int D)
 uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
 
 // LDS carve-up for (K, Dt, Lmax); returns total dynamic LDS bytes per workgroup
-size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, ddk::KernelArgs &A)
+size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk::KernelArgs &A)
 {
     const uint32_t NP = 64u * K;
     uint32_t o = 0;
@@ -76,10 +76,68 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, ddk::KernelArg
     {   // packed back-pointers: one word of K*(CB+1) bits per lane per read base (BtPack in hmm_kernel.hip)
         const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
         const uint32_t bytes = bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
-        A.lds_off_bt = wv;  wv += up16((uint32_t)Lmax * 64u * bytes);
+        A.lds_off_bt = wv;
+        if (!gbt) wv += up16((uint32_t)Lmax * 64u * bytes);   // GBT builds keep the tile in HBM scratch
     }
     A.lds_wave_bytes = wv;
     return (size_t)A.lds_shared_bytes + (size_t)waves * wv;
+}
+
+// waves per CU the register file allows for each K (kernel-resource-usage of the shipped builds)
+int reg_limited_waves_per_cu(int K) { return K <= 2 ? 12 : K == 3 ? 8 : 4; }
+
+uint32_t bt_word_bytes(int K, int Dt)
+{
+    const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
+    return bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+}
+
+// Launch plan: LDS-resident back-pointers when that keeps the CU as full as the registers allow, otherwise
+// the HBM-scratch build (GBT) with a persistent grid (one scratch tile per resident wave).
+struct Plan {
+    int K, Dt, waves, waves_per_cu;
+    bool gbt;
+    size_t lds, scratch_bytes;
+    unsigned grid_cap;       // 0 = one workgroup per item
+};
+
+int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, Plan &pl, ddk::KernelArgs &A)
+{
+    pl.K = pick_K(max_hap_len);
+    pl.Dt = pick_Dt(p->maxLengthDel + 1);
+    if (pl.K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
+    const int reg_cap = reg_limited_waves_per_cu(pl.K);
+    int best[2] = {0, 0}, bw[2] = {0, 0};
+    for (int gbt = 0; gbt < 2; gbt++) {
+        for (int wv = DD_WAVES; wv >= 1; wv--) {
+            ddk::KernelArgs tmp = A;
+            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, gbt != 0, tmp);
+            if (l > 160u * 1024u) continue;
+            int total = (int)((160u * 1024u) / l) * wv;
+            if (total > reg_cap) total = reg_cap;
+            if (total > best[gbt]) { best[gbt] = total; bw[gbt] = wv; }
+        }
+    }
+    if (best[0] == 0 && best[1] == 0)
+        return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length does not fit the LDS row buffers");
+    // HBM scratch costs a dependent global load per traceback step: use it only where LDS would leave the CU
+    // clearly emptier than the registers allow (measured: 8 of 12 waves -> LDS still wins by 19 %; 6 of 12 ->
+    // scratch wins by 26 %; tools/stress_sweep.py)
+    pl.gbt = best[0] == 0 || 3 * best[0] < 2 * best[1];
+#ifdef DD_FORCE_GBT
+    pl.gbt = DD_FORCE_GBT != 0 && best[1] > 0;
+#endif
+    pl.waves = bw[pl.gbt ? 1 : 0];
+    pl.waves_per_cu = best[pl.gbt ? 1 : 0];
+    pl.lds = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, pl.waves, pl.gbt, A);
+    pl.grid_cap = 0;
+    pl.scratch_bytes = 0;
+    if (pl.gbt) {
+        const int blocks_per_cu = (pl.waves_per_cu + pl.waves - 1) / pl.waves;
+        pl.grid_cap = 256u * (unsigned)blocks_per_cu;
+        pl.scratch_bytes = (size_t)pl.grid_cap * pl.waves * (size_t)max_read_len * 64u * bt_word_bytes(pl.K, pl.Dt);
+    }
+    return DD_SUCCESS;
 }
 
 int check_params(const dd_params *p)
@@ -277,9 +335,18 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
     return T_END;
 }
 
-size_t dd_workspace_bytes(const dd_params *, const dd_device_batch *) { return 0; }
+size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
+{
+    if (!p || !b || check_params(p) != DD_SUCCESS) return 0;
+    if (b->max_hap_len < 1 || b->max_read_len < 1) return 0;
+    Plan pl;
+    ddk::KernelArgs A;
+    memset(&A, 0, sizeof(A));
+    if (make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A) != DD_SUCCESS) return 0;
+    return pl.scratch_bytes;
+}
 
-int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *, size_t, void *stream)
+int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -288,10 +355,6 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     if (b->max_hap_len < 1 || b->max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype length outside [1,766]");
     if (b->max_read_len < 1 || b->max_read_len > DD_MAX_READ_LEN) return fail(DD_ERR_UNSUPPORTED, "read length outside [1,1024]");
     const int D = p->maxLengthDel + 1;
-    const int K = pick_K(b->max_hap_len);
-    const int Dt = pick_Dt(D);
-    if (K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
-
     ddk::KernelArgs A;
     memset(&A, 0, sizeof(A));
     A.n_windows = b->n_windows; A.n_haps = b->n_haps; A.n_reads = b->n_reads;
@@ -306,25 +369,16 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     A.dbg = g_dbg;
 #endif
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
-    // Waves per workgroup: whatever puts the most wavefronts on a CU given its 160 KiB of LDS (the
-    // back-pointer tile grows with read length x haplotype length); ties go to the larger workgroup,
-    // which amortises the per-haplotype setup over more reads.
-    int waves = 0;
-    size_t lds = 0;
-    {
-        int best_total = 0;
-        for (int wv = DD_WAVES; wv >= 1; wv--) {
-            ddk::KernelArgs tmp = A;
-            const size_t l = lds_layout(K, Dt, b->max_read_len, b->n_qual, wv, tmp);
-            if (l > 160u * 1024u) continue;
-            int blocks = (int)((160u * 1024u) / l);
-            int total = blocks * wv;
-            if (total > 32) total = 32;
-            if (total > best_total) { best_total = total; waves = wv; lds = l; }
-        }
-        if (waves == 0)
-            return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length needs more than 160 KiB of LDS per wavefront");
-        lds = lds_layout(K, Dt, b->max_read_len, b->n_qual, waves, A);
+    Plan pl;
+    rc = make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A);
+    if (rc) return rc;
+    const int K = pl.K, Dt = pl.Dt, waves = pl.waves;
+    const size_t lds = pl.lds;
+    if (pl.gbt) {
+        if (!workspace || workspace_bytes < pl.scratch_bytes)
+            return fail(DD_ERR_INVALID, "workspace too small for this shape: allocate dd_workspace_bytes() bytes");
+        A.bt_scratch = workspace;
+        A.bt_rows = b->max_read_len;
     }
     // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
     const int64_t target_blocks = 4096;
@@ -335,13 +389,16 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     A.n_split = (int32_t)split;
-    const int64_t grid = (int64_t)b->n_haps * split;
-    if (grid > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
-    g_last_launch[0] = K; g_last_launch[1] = Dt; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
+    const int64_t items = (int64_t)b->n_haps * split;
+    if (items > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    A.n_items = (int32_t)items;
+    int64_t grid = items;
+    if (pl.grid_cap && grid > pl.grid_cap) grid = pl.grid_cap;
+    g_last_launch[0] = K; g_last_launch[1] = Dt + (pl.gbt ? 100 : 0); g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(ddk::launch_hmm(K, Dt, A, (unsigned)grid, waves, lds, st));
+    HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
 }
@@ -427,7 +484,10 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
 #undef OUT
     if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
 
-    rc = dd_launch_device(p, &db, &dr, nullptr, 0, nullptr);
+    const size_t ws_bytes = dd_workspace_bytes(p, &db);
+    unsigned char *ws = nullptr;
+    if (ws_bytes && (rc = dev.alloc(&ws, ws_bytes))) return rc;
+    rc = dd_launch_device(p, &db, &dr, ws, ws_bytes, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
 #define DOWN(field, n) if (r->field && (n)) HIP_TRY(hipMemcpy(r->field, dr.field, (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost))

@@ -47,7 +47,8 @@ struct KernelArgs {
     /* params */
     int32_t D, maxLengthDel, padCover, bMid;
     /* launch geometry */
-    int32_t n_split;
+    int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
+    void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */
     uint32_t lds_off_E, lds_off_N, lds_off_Q, lds_shared_bytes, lds_wave_bytes;
@@ -55,7 +56,7 @@ struct KernelArgs {
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
 };
 
-hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
+hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 
 } // namespace ddk

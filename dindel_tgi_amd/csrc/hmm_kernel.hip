@@ -141,7 +141,11 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 #ifndef DD_MIN_WAVES_PER_SIMD
 #define DD_MIN_WAVES_PER_SIMD(K) ((K) <= 2 ? 3 : 1)
 #endif
-template <int K, int D>
+// GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
+// combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
+// tile is written once per read base (coalesced, one word per lane) and read back by the scalar traceback;
+// a few tens of MB for the whole chip, so it lives in L2 / Infinity Cache.
+template <int K, int D, bool GBT>
 __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,21 +154,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
     // wave index is uniform across the 64 lanes: tell the compiler, so that everything per read (offsets,
     // lengths, bMid, loop counters, the traceback chain) lives on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 4, 2 or 1 waves (host picks what fits LDS)
-
-    const int g = blockIdx.x / P.n_split;          // global haplotype index
-    const int split = blockIdx.x - g * P.n_split;
-    const int w = P.hap_window[g];
-    const int h0 = P.win_hap_off[w];
-    const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1];
-    const int R = r1 - r0;
-    const int hs_off = P.hap_seq_off[g];
-    const int Hs = P.hap_seq_off[g + 1] - hs_off;
-    const int numS = Hs + 2, RO = Hs + 1;
-    const uint32_t hapStart = P.win_hap_start[w];
+    const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 1..4 waves (host picks what fits LDS best)
     const int NP = 64 * K;
     const int Dr = P.D;                             // real D (== D unless the generic D=12 build is used)
-
     const double *T = P.tables;
     const double lLL = T[TC_LLL], lFL = T[TC_LFL], II = T[TC_II], NI = T[TC_NI], NN = T[TC_NN];
 
@@ -184,8 +176,32 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
     typedef BtPack<K, D> BP;
     typedef typename BtWord<BP::BYTES>::type btword_t;
-    btword_t *bt = reinterpret_cast<btword_t *>(wbase + P.lds_off_bt);    // [Lmax][64] packed back-pointers
+    btword_t *bt;                                                          // [Lmax][64] packed back-pointers
+    if constexpr (GBT)
+        bt = reinterpret_cast<btword_t *>(P.bt_scratch) + (size_t)(blockIdx.x * nwav + wave) * (size_t)P.bt_rows * 64;
+    else
+        bt = reinterpret_cast<btword_t *>(wbase + P.lds_off_bt);
 
+    for (int i = tid; i < 4 * P.n_qual; i += nthr) shQ[i] = T[T_QUAL + i];
+    // pads of the wave-private rows: written once, never touched again
+    if (lane < D) { rowA[lane] = make_double2(NEG_INF, 0.0); rowA[D + NP + lane] = make_double2(NEG_INF, 0.0); }
+    if (lane == 0) { rowI[0] = NEG_INF; rowI[1 + NP] = NEG_INF; }
+    STAMP_INIT;
+
+    // ======================= loop over this workgroup's (haplotype, read-slice) items =======================
+    for (int item = blockIdx.x; item < P.n_items; item += gridDim.x) {
+    __syncthreads();                               // every wave is done with the previous haplotype's LDS tables
+    const int g = item / P.n_split;                // global haplotype index
+    const int split = item - g * P.n_split;
+
+    const int w = P.hap_window[g];
+    const int h0 = P.win_hap_off[w];
+    const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1];
+    const int R = r1 - r0;
+    const int hs_off = P.hap_seq_off[g];
+    const int Hs = P.hap_seq_off[g + 1] - hs_off;
+    const int numS = Hs + 2, RO = Hs + 1;
+    const uint32_t hapStart = P.win_hap_start[w];
     const bool hap_ok = (P.maxLengthDel <= Hs);     // else "hapSize error." (ObservationModelFB.cpp:47)
 
     // ---- per-haplotype setup: state codes + homopolymer indel-error logs (setupTransitionProbs :1675-1703)
@@ -199,7 +215,6 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
         shE[s] = T[TC_EDEF];
         shN[s] = T[TC_NDEF];
     }
-    for (int s = tid; s < 4 * P.n_qual; s += nthr) shQ[s] = T[T_QUAL + s];
     __syncthreads();
     if (tid == 0) { shE[1] = T[T_HP + 2 * 1]; shN[1] = T[T_HP + 2 * 1 + 1]; }
     __syncthreads();
@@ -245,17 +260,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
 
-    // pads of the wave-private rows: written once, never touched again
-    if (lane < D) { rowA[lane] = make_double2(NEG_INF, 0.0); rowA[D + NP + lane] = make_double2(NEG_INF, 0.0); }
-    if (lane == 0) { rowI[0] = NEG_INF; rowI[1 + NP] = NEG_INF; }
-
     const int64_t pair_base = P.win_pair_off[w] + (int64_t)(g - h0) * R;
     const int rs_base = P.read_seq_off[r0];
     const int64_t SL = (int64_t)P.read_seq_off[r1] - rs_base;
     const int64_t hpos_base = P.win_hpos_off[w] + (int64_t)(g - h0) * SL;
     const int nv = P.hap_var_off ? (P.hap_var_off[g + 1] - P.hap_var_off[g]) : 0;
 
-    STAMP_INIT;
     STAMP(0);
     // ======================= loop over this wave's reads =======================
     for (int ri = split * nwav + wave; ri < R; ri += P.n_split * nwav) {
@@ -564,6 +574,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
         // round trips overlap.  Every lane walks redundantly (wave-uniform); lane 0 records.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (GBT) {
+            // the tile was written by all 64 lanes and is now read through another lane's address: make the
+            // stores visible at L2 and drop this CU's L1 copies of the tile (possibly stale from the previous read)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         {
             // the chain is wave-uniform: keep it on the scalar unit (readfirstlane) so the ~L dependent steps
             // cost no VALU issue slots beyond the LDS address move and the recorded state
@@ -726,6 +742,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
         // the next read reuses rdE/rdC/ms/bt of this wave: all of this pair's LDS reads precede (in program
         // order, same wave) the next pair's LDS writes, and DS ops of one wave execute in order.
     }
+    }   // item loop
 }
 
 // onHap[r] = 1 iff any haplotype of the window has !offHapHMQ for read r (DInDel.cpp:1710, 1720)
@@ -752,49 +769,54 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
     P.out.onHap[r] = (uint8_t)on;
 }
 
-template <int K, int D>
+template <int K, int D, bool GBT>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((dd_hmm_kernel<K, D>), grid, dim3(waves * 64), lds, st, A);
+    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT>), grid, dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }
 
-#ifdef DD_ONLY_K   // diagnostic builds: a single instantiation compiles in seconds
-hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+#ifdef DD_ONLY_K   // diagnostic builds: a single (K, D) compiles in seconds
+hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
     if (K != DD_ONLY_K || Dt != DD_ONLY_D) return hipErrorInvalidValue;
-    return launch_one<DD_ONLY_K, DD_ONLY_D>(A, dim3(grid), waves, lds, st);
+    return gbt ? launch_one<DD_ONLY_K, DD_ONLY_D, true>(A, dim3(grid), waves, lds, st)
+               : launch_one<DD_ONLY_K, DD_ONLY_D, false>(A, dim3(grid), waves, lds, st);
 }
 #else
-template <int D>
+template <int D, bool GBT>
 static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
     switch (K) {
-    case 1: return launch_one<1, D>(A, grid, waves, lds, st);
-    case 2: return launch_one<2, D>(A, grid, waves, lds, st);
-    case 3: return launch_one<3, D>(A, grid, waves, lds, st);
-    case 4: return launch_one<4, D>(A, grid, waves, lds, st);
-    case 6: return launch_one<6, D>(A, grid, waves, lds, st);
-    case 8: return launch_one<8, D>(A, grid, waves, lds, st);
-    case 12: return launch_one<12, D>(A, grid, waves, lds, st);
+    case 1: return launch_one<1, D, GBT>(A, grid, waves, lds, st);
+    case 2: return launch_one<2, D, GBT>(A, grid, waves, lds, st);
+    case 3: return launch_one<3, D, GBT>(A, grid, waves, lds, st);
+    case 4: return launch_one<4, D, GBT>(A, grid, waves, lds, st);
+    case 6: return launch_one<6, D, GBT>(A, grid, waves, lds, st);
+    case 8: return launch_one<8, D, GBT>(A, grid, waves, lds, st);
+    case 12: return launch_one<12, D, GBT>(A, grid, waves, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_hmm(int K, int Dt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+template <bool GBT>
+static hipError_t launch_d(int K, int Dt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
-    dim3 g(grid);
     switch (Dt) {
-    case 6: return launch_k<6>(K, A, g, waves, lds, st);
-    case 11: return launch_k<11>(K, A, g, waves, lds, st);
-    case 12: return launch_k<12>(K, A, g, waves, lds, st);
+    case 6: return launch_k<6, GBT>(K, A, g, waves, lds, st);
+    case 11: return launch_k<11, GBT>(K, A, g, waves, lds, st);
+    case 12: return launch_k<12, GBT>(K, A, g, waves, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
 
+hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+{
+    return gbt ? launch_d<true>(K, Dt, A, dim3(grid), waves, lds, st) : launch_d<false>(K, Dt, A, dim3(grid), waves, lds, st);
+}
 #endif
 
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)

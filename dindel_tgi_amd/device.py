@@ -68,14 +68,17 @@ class DeviceBatch:
             setattr(dr, k, self.out[k].data_ptr())
         self.dr = dr
         self._n = n
+        # device scratch the launch needs for this shape (back-pointer tiles in HBM for long reads); 0 if none
+        self.ws_bytes = int(lib.dd_workspace_bytes(C.byref(params), C.byref(db)))
+        self.ws = torch.empty(max(self.ws_bytes, 8), dtype=torch.uint8, device=self.device)
 
     def launch(self, stream=None):
         """Enqueue the path on `stream` (default: torch's current stream on this device). Asynchronous."""
         lib = capi.load()
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
-        rc = lib.dd_launch_device(C.byref(self.params), C.byref(self.db), C.byref(self.dr), None, 0,
-                                  C.c_void_p(stream.cuda_stream))
+        rc = lib.dd_launch_device(C.byref(self.params), C.byref(self.db), C.byref(self.dr),
+                                  C.c_void_p(self.ws.data_ptr()), self.ws_bytes, C.c_void_p(stream.cuda_stream))
         if rc != 0:
             raise RuntimeError("dd_launch_device rc=%d: %s" % (rc, capi.last_error()))
 

@@ -161,10 +161,23 @@ def test_all_lane_tilings(lib, hs, L, n):
     check(lib, [Window(1000, [hap], reads_from(hap, n, min(L, 100)))], p)
 
 
-def test_shapes_beyond_lds_are_refused_not_miscomputed(lib):
+def test_maximum_shape_runs_with_hbm_backpointers(lib):
+    """766-bp haplotype x 1024-bp reads: the back-pointer tile (512 KiB per pair) cannot live in LDS; the library
+    switches to the HBM-scratch build and the result is still bit-equal to the oracle."""
     hap = rnd(766)
-    pb = pack([Window(1000, [hap], reads_from(hap, 1, 1000))])
-    arrs, res = alloc_result(pb)
-    b = pb.ctypes_batch()
+    var = hap[:300] + hap[304:]
+    reads = reads_from(hap, 2, 1024, junk=0.0) + reads_from(var, 1, 1000, junk=0.0) + reads_from(hap, 1, 37)
+    pb, got = check(lib, [Window(1000, [hap, var], reads)])
+    assert capi.last_launch()["D"] >= 100                   # HBM-scratch build was selected
+    pb, got = check(lib, [Window(1000, [hap[:400]], reads_from(hap[:400], 3, 600, junk=0.0))], capi.params_struct_defaults())
+    assert capi.last_launch()["D"] >= 100
+
+
+def test_long_reads_config5_shape(lib):
+    """BASELINE configs[4] shape (250-bp reads, maxLengthDel=10) at small scale."""
     p = capi.params_cli_defaults()
-    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    p.maxLengthDel = 10
+    for hs in (120, 160, 200):
+        hap = rnd(hs)
+        haps = [hap, hap[:hs // 2] + hap[hs // 2 + 3:], hap[:hs // 2] + "ACG" + hap[hs // 2:]]
+        check(lib, [Window(1000, haps, reads_from(hap, 6, 250) + reads_from(haps[1], 6, 250))], p)

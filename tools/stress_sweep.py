@@ -34,9 +34,10 @@ for pt in points:
     assert int((dev.out["status"][:pb.n_pairs] != 0).sum()) == 0
     g = capi.last_launch()
     blocks_cu = min((160 * 1024) // g["lds_block"], 32 // g["waves"])
+    reg_cap = 12 if g["K"] <= 2 else 8 if g["K"] == 3 else 4
     bpp = 4.0 * pt["L"] + 48 + pb.max_hap_len / pt["R"]
     print(json.dumps(dict(point=pt, pairs=pb.n_pairs, ms=ms, cells_per_s=pb.cells / ms * 1e3, pairs_per_s=pb.n_pairs / ms * 1e3,
-                          K=g["K"], D_build=g["D"], waves_per_wg=g["waves"], lds_per_wave=g["lds_wave"], lds_per_wg=g["lds_block"],
-                          waves_per_cu_by_lds=blocks_cu * g["waves"], hbm_GBps_algorithmic=bpp * pb.n_pairs / ms / 1e6,
+                          K=g["K"], D_build=g["D"] % 100, backpointers="hbm-scratch" if g["D"] >= 100 else "lds", scratch_MB=dev.ws_bytes / 1e6, waves_per_wg=g["waves"], lds_per_wave=g["lds_wave"], lds_per_wg=g["lds_block"],
+                          waves_per_cu_by_lds=blocks_cu * g["waves"], waves_per_cu_by_regs=reg_cap, hbm_GBps_algorithmic=bpp * pb.n_pairs / ms / 1e6,
                           hbm_frac=bpp * pb.n_pairs / ms / 1e6 / 8000.0)))
     del dev
