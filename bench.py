@@ -97,15 +97,23 @@ def main():
     ap.add_argument("--hap-len", type=int, default=120)
     ap.add_argument("--max-length-del", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0 (checks the N>1 code path; "
+                         "the number it prints is not a multi-GPU measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the likelihood path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -119,15 +127,22 @@ def main():
     dev = DeviceBatch(pb, params, device)
     n_pairs, cells = pb.n_pairs, pb.cells
 
+    GATHER = ("ll", "offHap", "offHapHMQ")          # per-pair records the downstream reduction consumes
     gather_bufs = None
     if world > 1 and rank == 0:
-        gather_bufs = {k: [torch.empty_like(dev.out[k]) for _ in range(world)] for k in ("ll", "offHap", "offHapHMQ")}
+        gdev = "cpu" if args.rehearse else device
+        gather_bufs = {k: [torch.empty(dev.out[k].shape, dtype=dev.out[k].dtype, device=gdev) for _ in range(world)]
+                       for k in GATHER}
+
+    def gather():
+        for k in GATHER:
+            src = dev.out[k].cpu() if args.rehearse else dev.out[k]
+            dist.gather(src, gather_bufs[k] if rank == 0 else None, dst=0)
 
     def step():
         dev.launch()
         if world > 1:
-            for k in ("ll", "offHap", "offHapHMQ"):
-                dist.gather(dev.out[k], gather_bufs[k] if rank == 0 else None, dst=0)
+            gather()
 
     for _ in range(args.warmup):
         step()
@@ -142,15 +157,14 @@ def main():
         dev.launch()
         ev[i][1].record()
         if world > 1:
-            for k in ("ll", "offHap", "offHapHMQ"):
-                dist.gather(dev.out[k], gather_bufs[k] if rank == 0 else None, dst=0)
+            gather()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
@@ -160,6 +174,9 @@ def main():
     assert int((res_status != 0).sum().item()) == 0, "non-OK pair status in the bench batch"
     assert bool(torch.isfinite(dev.out["ll"][:n_pairs]).all().item())
 
+    if world > 1 and rank == 0:
+        # the gathered block of rank 0 is its own result (sanity of the collective's layout)
+        assert torch.equal(gather_bufs["ll"][0][:n_pairs].cpu(), dev.out["ll"][:n_pairs].cpu())
     if rank == 0:
         total_cells = cells * world * args.steps
         total_windows = args.windows * world * args.steps
