@@ -98,7 +98,8 @@ class dd_device_result(C.Structure):
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
            "dd_compute_likelihoods", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
-           "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_last_error", "dd_abi_version", "dd_device_count"]
+           "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
+           "dd_pair_sums", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
 _lib = None
 
@@ -132,6 +133,9 @@ def load():
     lib.dd_workspace_bytes.restype = C.c_size_t
     lib.dd_launch_device.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch), C.POINTER(dd_device_result),
                                      C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dd_pair_sum_offsets.argtypes = [C.POINTER(dd_batch), c_i64p]
+    lib.dd_pair_sums_device.argtypes = [C.POINTER(dd_device_batch), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dd_pair_sums.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p, C.c_int]
     lib.dd_last_launch.argtypes = [C.POINTER(C.c_int32 * 8)]
     lib.dd_last_launch.restype = None
     lib.dd_kernel_name.restype = C.c_char_p

@@ -403,6 +403,68 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     return DD_SUCCESS;
 }
 
+int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off)
+{
+    if (!b || !win_hh_off) return fail(DD_ERR_INVALID, "null argument");
+    int64_t o = 0;
+    for (int w = 0; w < b->n_windows; w++) {
+        win_hh_off[w] = o;
+        const int64_t H = b->win_hap_off[w + 1] - b->win_hap_off[w];
+        o += H * H;
+    }
+    win_hh_off[b->n_windows] = o;
+    return DD_SUCCESS;
+}
+
+int dd_pair_sums_device(const dd_device_batch *b, const int64_t *win_hh_off_dev, int64_t n_slots,
+                        const double *ll_dev, double *out_dev, void *stream)
+{
+    if (!b || !win_hh_off_dev || !ll_dev || !out_dev) return fail(DD_ERR_INVALID, "null argument");
+    ddk::PairSumArgs A;
+    A.n_windows = b->n_windows; A.n_slots = n_slots;
+    A.win_hap_off = b->win_hap_off; A.win_read_off = b->win_read_off; A.win_pair_off = b->win_pair_off;
+    A.win_hh_off = win_hh_off_dev; A.ll = ll_dev; A.out = out_dev;
+    if ((n_slots + 3) / 4 > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    HIP_TRY(ddk::launch_pair_sums(A, static_cast<hipStream_t>(stream)));
+    return DD_SUCCESS;
+}
+
+int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int device)
+{
+    dd_sizes sz;
+    int rc = dd_batch_sizes(b, &sz);
+    if (rc) return rc;
+    if (!ll_host || !out_host) return fail(DD_ERR_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DD_ERR_NO_DEVICE, "no HIP device: the genotype read-sum has no CPU fallback in this library");
+    if (device < 0 || device >= ndev) return fail(DD_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    const int W = b->n_windows;
+    std::vector<int64_t> pair_off(W + 1), hh_off(W + 1);
+    dd_batch_offsets(b, pair_off.data(), nullptr, nullptr);
+    dd_pair_sum_offsets(b, hh_off.data());
+    if (hh_off[W] == 0) return DD_SUCCESS;
+    DevBuf dev;
+    dd_device_batch db;
+    memset(&db, 0, sizeof(db));
+    db.n_windows = W;
+    if ((rc = dev.upload(&db.win_hap_off, b->win_hap_off, (size_t)W + 1))) return rc;
+    if ((rc = dev.upload(&db.win_read_off, b->win_read_off, (size_t)W + 1))) return rc;
+    if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
+    const int64_t *hh_dev = nullptr;
+    const double *ll_dev = nullptr;
+    double *out_dev = nullptr;
+    if ((rc = dev.upload(&hh_dev, (const int64_t *)hh_off.data(), hh_off.size()))) return rc;
+    if ((rc = dev.upload(&ll_dev, ll_host, (size_t)sz.n_pairs))) return rc;
+    if ((rc = dev.alloc(&out_dev, (size_t)hh_off[W]))) return rc;
+    rc = dd_pair_sums_device(&db, hh_dev, hh_off[W], ll_dev, out_dev, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_host, out_dev, (size_t)hh_off[W] * sizeof(double), hipMemcpyDeviceToHost));
+    return DD_SUCCESS;
+}
+
 int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
     int rc = check_params(p);

@@ -59,5 +59,16 @@ struct KernelArgs {
 hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 
+/* N1: per-window haplotype-pair read sums (genotype_kernel.hip) */
+struct PairSumArgs {
+    int32_t n_windows;
+    int64_t n_slots;                 /* sum over windows of H_w^2 */
+    const int32_t *win_hap_off, *win_read_off;
+    const int64_t *win_pair_off, *win_hh_off;
+    const double *ll;                /* per pair, liks[h][r] order */
+    double *out;                     /* [n_slots]: window w, slot h1*H_w+h2 (h1<=h2) */
+};
+hipError_t launch_pair_sums(const PairSumArgs &A, hipStream_t st);
+
 } // namespace ddk
 #endif

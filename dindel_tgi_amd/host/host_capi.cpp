@@ -5,6 +5,7 @@
 #include <sstream>
 #include <string>
 #include "compute_likelihoods.hpp"
+#include "genotype.hpp"
 
 using namespace dindel;
 
@@ -115,6 +116,25 @@ int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const dou
         return emit(os.str(), out, cap);
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// N1 host step: returns {max_indel_pair, max_noindel_pair, max_ll_indel, max_ll_noindel, qual} or -1 on the
+// reference's "Could not find indel allele" throw
+int ddh_pair_posteriors(int nh, const double *pair_sum, const double *prior, const int *filtered, const int *ncand,
+                        double *posterior_out, int *pairs_out, double *vals_out)
+{
+    try {
+        std::vector<double> ps(pair_sum, pair_sum + nh * nh), pr(prior, prior + nh * nh);
+        std::vector<int> f(filtered, filtered + nh), nc(ncand, ncand + nh);
+        PairPosteriorResult R = diploidPairPosteriors(nh, ps, pr, f, nc);
+        for (int i = 0; i < nh * nh; i++) posterior_out[i] = R.pairs_posterior[i];
+        pairs_out[0] = R.max_indel_pair[0]; pairs_out[1] = R.max_indel_pair[1];
+        pairs_out[2] = R.max_noindel_pair[0]; pairs_out[3] = R.max_noindel_pair[1];
+        vals_out[0] = R.max_ll_indel; vals_out[1] = R.max_ll_noindel; vals_out[2] = R.qual;
+        return 0;
+    } catch (std::string &e) {
+        return -1;
     }
 }
 

@@ -184,6 +184,17 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b);
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- N1 (next row): read sums of the diploid genotype reduction --------------------------- */
+/* S[w][h1*H_w+h2] (h1<=h2) = sum over the window's reads, in order, of log(0.5)+addLogs(ll[h1][r], ll[h2][r])
+ * — the inner loop of DetInDel::diploidGLF, reference DInDel.cpp:3085-3091 (and :3372-3374); addLogs is
+ * reference Utils.hpp:29-38.  `ll` is the per-pair array dd_launch_device / dd_compute_likelihoods produced.
+ * win_hh_off[n_windows+1] = prefix sums of H_w^2 (dd_pair_sum_offsets).  exp/log run on the device:
+ * agreement with glibc is ~1e-15 relative, not bit-for-bit. */
+int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off);
+int dd_pair_sums_device(const dd_device_batch *b, const int64_t *win_hh_off_dev, int64_t n_slots,
+                        const double *ll_dev, double *out_dev, void *stream);
+int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int device);
+
 /* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
 const char *dd_kernel_name(void);
 /* geometry of the last dd_launch_device on this host thread's library instance:

@@ -492,3 +492,38 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
     free(pair_off); free(hpos_off); free(vc_off);
     return 0;
 }
+
+/* ---- N1: read sums of the diploid genotype reduction (reference DInDel.cpp:3085-3091, Utils.hpp:29-38) ---- */
+static double add_logs(const double l1, const double l2)
+{
+    if (l1 > l2) {
+        double diff = l2 - l1;
+        return l1 + log(1.0 + exp(diff));
+    } else {
+        double diff = l1 - l2;
+        return l2 + log(1.0 + exp(diff));
+    }
+}
+
+/* out[win_hh_off[w] + h1*H+h2] for h1<=h2; lower triangle set to 0 */
+int ddo_pair_sums(const dd_batch *B, const double *ll, double *out)
+{
+    int64_t pair_off = 0, hh = 0;
+    int w;
+    for (w = 0; w < B->n_windows; w++) {
+        int H = B->win_hap_off[w + 1] - B->win_hap_off[w];
+        int R = B->win_read_off[w + 1] - B->win_read_off[w];
+        int h1, h2, r;
+        for (h1 = 0; h1 < H; h1++)
+            for (h2 = 0; h2 < H; h2++) {
+                double s = 0.0;
+                if (h2 >= h1)
+                    for (r = 0; r < R; r++)
+                        s += log(0.5) + add_logs(ll[pair_off + (int64_t)h1 * R + r], ll[pair_off + (int64_t)h2 * R + r]);
+                out[hh + (int64_t)h1 * H + h2] = s;
+            }
+        pair_off += (int64_t)H * R;
+        hh += (int64_t)H * H;
+    }
+    return 0;
+}

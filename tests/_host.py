@@ -18,7 +18,8 @@ def load():
     global _lib
     if _lib is None:
         capi.load()                     # libdindel_hmm.so (and torch's HIP runtime) first
-        if not os.path.exists(LIB):
+        srcs = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith((".cpp", ".hpp"))]
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-s", "-C", HOST_DIR])
         _lib = C.CDLL(LIB)
     return _lib

@@ -40,6 +40,7 @@ def load():
         _lib.ddo_pair.argtypes = [C.c_char_p, C.c_int, C.c_char_p, capi.c_f64p, C.c_int, C.c_double, C.c_uint32,
                                   C.c_uint32, C.c_int, C.POINTER(capi.dd_params), C.POINTER(ddo_out),
                                   C.POINTER(C.c_int)]
+        _lib.ddo_pair_sums.argtypes = [C.POINTER(capi.dd_batch), capi.c_f64p, capi.c_f64p]
         _lib.ddo_batch.argtypes = [C.POINTER(capi.dd_params), C.POINTER(capi.dd_batch), C.POINTER(capi.dd_result),
                                    C.c_int, C.c_int64, C.c_int64]
     return _lib
