@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--hap-len", type=int, default=120)
     ap.add_argument("--max-length-del", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-api", action="store_true",
+                    help="also time dd_compute_likelihoods (host pointers in/out: H2D + kernels + D2H) once and report it "
+                         "as host_api; never used for `value`")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0 (checks the N>1 code path; "
                          "the number it prints is not a multi-GPU measurement)")
@@ -207,6 +210,19 @@ def main():
             "valu_fp64": {"achieved_cells_per_s": cells / (kern_ms * 1e-3), "ceiling_cells_per_s": VALU_CELLS_PER_S,
                           "frac": cells / (kern_ms * 1e-3) / VALU_CELLS_PER_S},
         }
+        if args.host_api:
+            import ctypes as C
+            from dindel_tgi_amd.batch import alloc_result
+            lib = capi.load()
+            arrs, res = alloc_result(pb)
+            hb = pb.ctypes_batch()
+            for _ in range(2):                      # second call: page tables of the result arrays are warm
+                t0 = time.perf_counter()
+                rc = lib.dd_compute_likelihoods(C.byref(params), C.byref(hb), C.byref(res), local_rank)
+                dt = time.perf_counter() - t0
+                assert rc == 0, capi.last_error()
+            out["host_api"] = {"seconds": dt, "cells_per_s": cells / dt, "windows_per_s": args.windows / dt,
+                               "note": "dd_compute_likelihoods with host pointers: H2D of the batch, kernels, D2H of every output"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pb, params)
         print(json.dumps(out))

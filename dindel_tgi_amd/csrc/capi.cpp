@@ -346,7 +346,10 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
     return pl.scratch_bytes;
 }
 
-int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
+// Enqueue the path for haplotypes [hap_begin, hap_end) and reads [read_begin, read_end) of the batch (a
+// contiguous block of windows); hap_end < 0 means the whole batch.
+static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes,
+                        void *stream, int hap_begin, int hap_end, int read_begin, int read_end)
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -389,10 +392,13 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     A.n_split = (int32_t)split;
-    const int64_t items = (int64_t)b->n_haps * split;
-    if (items > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
-    A.n_items = (int32_t)items;
-    int64_t grid = items;
+    if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
+    if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    A.item_begin = (int32_t)(hap_begin * split);
+    A.n_items = (int32_t)(hap_end * split);
+    A.read_begin = read_begin; A.read_end = read_end;
+    int64_t grid = (int64_t)(hap_end - hap_begin) * split;
+    if (grid <= 0) return DD_SUCCESS;
     if (pl.grid_cap && grid > pl.grid_cap) grid = pl.grid_cap;
     g_last_launch[0] = K; g_last_launch[1] = Dt + (pl.gbt ? 100 : 0); g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
@@ -401,6 +407,11 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
     HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
+}
+
+int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return launch_range(p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
 }
 
 int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off)
@@ -546,17 +557,56 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
 #undef OUT
     if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
 
+    // Chunked, double-buffered execution: contiguous window blocks alternate between two streams, and the D2H
+    // of block c is issued after the kernel of block c+1 has been enqueued, so the copy engine drains results
+    // while the CUs work on the next block (with pageable user memory the copy call blocks the host thread, not
+    // the GPU).  Each stream has its own back-pointer scratch.
     const size_t ws_bytes = dd_workspace_bytes(p, &db);
-    unsigned char *ws = nullptr;
-    if (ws_bytes && (rc = dev.alloc(&ws, ws_bytes))) return rc;
-    rc = dd_launch_device(p, &db, &dr, ws, ws_bytes, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-#define DOWN(field, n) if (r->field && (n)) HIP_TRY(hipMemcpy(r->field, dr.field, (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost))
-    DOWN(ll, np); DOWN(llOn, np); DOWN(llOff, np); DOWN(mLogBQ, np); DOWN(offHap, np); DOWN(offHapHMQ, np);
-    DOWN(numIndels, np); DOWN(numMismatch, np); DOWN(nBQT, np); DOWN(nmmBQT, np); DOWN(nMMLeft, np); DOWN(nMMRight, np);
-    DOWN(firstBase, np); DOWN(lastBase, np); DOWN(hpos, sz.hpos_len); DOWN(var_covered, sz.var_cov_len);
-    DOWN(status, np); DOWN(onHap, sz.n_reads);
+    unsigned char *ws[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++)
+        if (ws_bytes && (rc = dev.alloc(&ws[i], ws_bytes))) return rc;
+    struct Streams {
+        hipStream_t s[2] = {nullptr, nullptr};
+        ~Streams() { for (int i = 0; i < 2; i++) if (s[i]) (void)hipStreamDestroy(s[i]); }
+    } streams;
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&streams.s[i], hipStreamNonBlocking));
+    HIP_TRY(hipDeviceSynchronize());           // inputs were uploaded on the null stream
+
+    int n_chunks = (int)((sz.n_pairs + 999999) / 1000000);
+    if (n_chunks > 64) n_chunks = 64;
+    if (n_chunks > W) n_chunks = W;
+    if (n_chunks < 1) n_chunks = 1;
+    std::vector<int> cw(n_chunks + 1, 0);      // window boundaries with ~equal pair counts
+    for (int c = 1; c < n_chunks; c++) {
+        const int64_t target = sz.n_pairs * c / n_chunks;
+        int w = cw[c - 1];
+        while (w < W && pair_off[w] < target) w++;
+        cw[c] = w;
+    }
+    cw[n_chunks] = W;
+#define DOWN(field, off, n) if (r->field && (n)) HIP_TRY(hipMemcpyAsync(r->field + (off), dr.field + (off), (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost, st))
+    auto download = [&](int c) -> int {
+        hipStream_t st = streams.s[c & 1];
+        const int w0 = cw[c], w1 = cw[c + 1];
+        const int64_t p0 = pair_off[w0], pn = pair_off[w1] - p0;
+        DOWN(ll, p0, pn); DOWN(llOn, p0, pn); DOWN(llOff, p0, pn); DOWN(mLogBQ, p0, pn); DOWN(offHap, p0, pn); DOWN(offHapHMQ, p0, pn);
+        DOWN(numIndels, p0, pn); DOWN(numMismatch, p0, pn); DOWN(nBQT, p0, pn); DOWN(nmmBQT, p0, pn); DOWN(nMMLeft, p0, pn);
+        DOWN(nMMRight, p0, pn); DOWN(firstBase, p0, pn); DOWN(lastBase, p0, pn); DOWN(status, p0, pn);
+        DOWN(hpos, hpos_off[w0], hpos_off[w1] - hpos_off[w0]);
+        DOWN(var_covered, vc_off[w0], vc_off[w1] - vc_off[w0]);
+        DOWN(onHap, b->win_read_off[w0], b->win_read_off[w1] - b->win_read_off[w0]);
+        return DD_SUCCESS;
+    };
+    for (int c = 0; c < n_chunks; c++) {
+        const int w0 = cw[c], w1 = cw[c + 1];
+        rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], b->win_hap_off[w0], b->win_hap_off[w1],
+                          b->win_read_off[w0], b->win_read_off[w1]);
+        if (rc) return rc;
+        if (c > 0 && (rc = download(c - 1))) return rc;
+    }
+    if ((rc = download(n_chunks - 1))) return rc;
+    HIP_TRY(hipStreamSynchronize(streams.s[0]));
+    HIP_TRY(hipStreamSynchronize(streams.s[1]));
 #undef DOWN
     return DD_SUCCESS;
 }

@@ -48,6 +48,8 @@ struct KernelArgs {
     int32_t D, maxLengthDel, padCover, bMid;
     /* launch geometry */
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
+    int32_t item_begin;                  /* this launch covers items [item_begin, n_items) (chunked host path) */
+    int32_t read_begin, read_end;        /* reads covered by this launch (onHap kernel) */
     void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */

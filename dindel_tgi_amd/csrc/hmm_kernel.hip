@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
     STAMP_INIT;
 
     // ======================= loop over this workgroup's (haplotype, read-slice) items =======================
-    for (int item = blockIdx.x; item < P.n_items; item += gridDim.x) {
+    for (int item = P.item_begin + blockIdx.x; item < P.n_items; item += gridDim.x) {
     __syncthreads();                               // every wave is done with the previous haplotype's LDS tables
     const int g = item / P.n_split;                // global haplotype index
     const int split = item - g * P.n_split;
@@ -748,8 +748,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
 // onHap[r] = 1 iff any haplotype of the window has !offHapHMQ for read r (DInDel.cpp:1710, 1720)
 __global__ void dd_onhap_kernel(const KernelArgs P)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.n_reads) return;
+    const int r = P.read_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.read_end) return;
     // window of read r: binary search in win_read_off
     int lo = 0, hi = P.n_windows;
     while (hi - lo > 1) {
@@ -821,8 +821,9 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned gri
 
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)
 {
-    if (A.n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(dd_onhap_kernel, dim3((A.n_reads + 255) / 256), dim3(256), 0, st, A);
+    const int n = A.read_end - A.read_begin;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dd_onhap_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
     return hipGetLastError();
 }
 
