@@ -84,7 +84,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
 }
 
 // waves per CU the register file allows for each K (kernel-resource-usage of the shipped builds)
-int reg_limited_waves_per_cu(int K) { return K <= 2 ? 12 : K == 3 ? 8 : 4; }
+int reg_limited_waves_per_cu(int K, int Dt, bool gbt) { return K <= 2 ? ((Dt <= 7 || gbt) ? 12 : 8) : K == 3 ? (Dt <= 7 ? 8 : 4) : 4; }
 
 uint32_t bt_word_bytes(int K, int Dt)
 {
@@ -106,9 +106,9 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     pl.K = pick_K(max_hap_len);
     pl.Dt = pick_Dt(p->maxLengthDel + 1);
     if (pl.K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
-    const int reg_cap = reg_limited_waves_per_cu(pl.K);
     int best[2] = {0, 0}, bw[2] = {0, 0};
     for (int gbt = 0; gbt < 2; gbt++) {
+        const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0);
         for (int wv = DD_WAVES; wv >= 1; wv--) {
             ddk::KernelArgs tmp = A;
             const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, gbt != 0, tmp);

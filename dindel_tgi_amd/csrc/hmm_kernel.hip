@@ -136,17 +136,19 @@ template <> struct BtWord<2> { typedef uint16_t type; };
 template <> struct BtWord<4> { typedef uint32_t type; };
 template <> struct BtWord<8> { typedef uint64_t type; };
 
-// Occupancy target (waves per SIMD) the register allocator is held to: measured +20 % going from 2 to 3
-// waves/SIMD at K<=2 (the VALU is the bound and two waves cannot keep it issuing).
+// Occupancy target (waves per SIMD) the register allocator is held to.  Measured (tools/ab_point.py): K<=2, D<=7
+// +20 % going from 2 to 3 waves/SIMD (the VALU is the bound and two waves cannot keep it issuing); K=2, D=11
+// needs ~236 VGPRs unspilled: the HBM-scratch build still gains 14 % at 3 waves with spills, the LDS build is
+// LDS-limited to 2 waves/SIMD anyway and loses 7 % to the spills, so it stays at 2.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K) ((K) <= 2 ? 3 : 1)
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : 1)
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
 // tile is written once per read base (coalesced, one word per lane) and read back by the scalar traceback;
 // a few tens of MB for the whole chip, so it lives in L2 / Infinity Cache.
 template <int K, int D, bool GBT>
-__global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hmm_kernel(const KernelArgs P)
+__global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT)) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -588,50 +590,64 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K)) dd_hm
             const int nL = bMid, nR = L - 1 - bMid;
             const int n = nL > nR ? nL : nR;
             const unsigned chmask = (1u << BP::CB) - 1u, insbit = 1u << BP::CB;
-            for (int i = 0; i < n; i++) {
-                if (i < nL) {                                 // mapState[b-1] = btf[b][mapState[b]]
-                    const int b = bMid - i;
-                    const bool ins = sL >= numS;
-                    const int x = ins ? sL - numS : sL;
-                    const btword_t wv = bt[b * 64 + x / K];
-                    unsigned byte;
-                    if (sizeof(btword_t) == 8) {
-                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(wv & 0xffffffffu));
-                        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)wv >> 32));
-                        byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
-                    } else {
-                        byte = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)wv) >> ((x % K) * BP::PB);
-                    }
-                    const unsigned ch = byte & chmask;
-                    int p;
-                    if (ins) p = (byte & insbit) ? x : sL;
-                    else if (x == 0) p = 0;
-                    else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
-                    else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
-                    sL = p;
-                    if (lane == 0) ms[b - 1] = (int16_t)p;
+            // Whole back-pointer rows are fetched TB rows ahead for both chains (their addresses do not depend on
+            // the chain: lane l reads word l of the row), so the dependent part of each step is a v_readlane, not a
+            // memory round trip — one LDS / L2 latency per TB steps instead of per step.
+            constexpr int TB = 8;
+            for (int i0 = 0; i0 < n; i0 += TB) {
+                btword_t rowL[TB], rowR[TB];
+#pragma unroll
+                for (int j = 0; j < TB; j++) {
+                    rowL[j] = (i0 + j < nL) ? bt[(bMid - (i0 + j)) * 64 + lane] : (btword_t)0;
+                    rowR[j] = (i0 + j < nR) ? bt[(bMid + (i0 + j) + 1) * 64 + lane] : (btword_t)0;
                 }
-                if (i < nR) {                                 // mapState[b+1] = btb[b][mapState[b]] (stored at row b+1)
-                    const int b = bMid + i;
-                    const bool ins = sR >= numS;
-                    const int x = ins ? sR - numS : sR;
-                    const btword_t wv = bt[(b + 1) * 64 + x / K];
-                    unsigned byte;
-                    if (sizeof(btword_t) == 8) {
-                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(wv & 0xffffffffu));
-                        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)wv >> 32));
-                        byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
-                    } else {
-                        byte = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)wv) >> ((x % K) * BP::PB);
+#pragma unroll
+                for (int j = 0; j < TB; j++) {
+                    const int i = i0 + j;
+                    if (i < nL) {                             // mapState[b-1] = btf[b][mapState[b]]
+                        const int b = bMid - i;
+                        const bool ins = sL >= numS;
+                        const int x = ins ? sL - numS : sL;
+                        const int src = x / K;
+                        unsigned byte;
+                        if (sizeof(btword_t) == 8) {
+                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowL[j] & 0xffffffffu), src);
+                            const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowL[j] >> 32), src);
+                            byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
+                        } else {
+                            byte = (unsigned)__builtin_amdgcn_readlane((unsigned)rowL[j], src) >> ((x % K) * BP::PB);
+                        }
+                        const unsigned ch = byte & chmask;
+                        int p;
+                        if (ins) p = (byte & insbit) ? x : sL;
+                        else if (x == 0) p = 0;
+                        else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
+                        else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
+                        sL = p;
+                        if (lane == 0) ms[b - 1] = (int16_t)p;
                     }
-                    const unsigned ch = byte & chmask;
-                    int p;
-                    if (ins) p = (byte & insbit) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
-                    else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
-                    else if (x == RO) p = (ch == 0) ? RO : numS + RO;
-                    else p = (ch == 0) ? numS + x : x + (int)ch;
-                    sR = p;
-                    if (lane == 0) ms[b + 1] = (int16_t)p;
+                    if (i < nR) {                             // mapState[b+1] = btb[b][mapState[b]] (stored at row b+1)
+                        const int b = bMid + i;
+                        const bool ins = sR >= numS;
+                        const int x = ins ? sR - numS : sR;
+                        const int src = x / K;
+                        unsigned byte;
+                        if (sizeof(btword_t) == 8) {
+                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowR[j] & 0xffffffffu), src);
+                            const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowR[j] >> 32), src);
+                            byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
+                        } else {
+                            byte = (unsigned)__builtin_amdgcn_readlane((unsigned)rowR[j], src) >> ((x % K) * BP::PB);
+                        }
+                        const unsigned ch = byte & chmask;
+                        int p;
+                        if (ins) p = (byte & insbit) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
+                        else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
+                        else if (x == RO) p = (ch == 0) ? RO : numS + RO;
+                        else p = (ch == 0) ? numS + x : x + (int)ch;
+                        sR = p;
+                        if (lane == 0) ms[b + 1] = (int16_t)p;
+                    }
                 }
             }
         }
