@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -371,6 +372,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
 #ifdef DD_STAMPS
     A.dbg = g_dbg;
 #endif
+    A.always_ro = getenv("DD_ALWAYS_RO") ? 1 : 0;
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
     Plan pl;
     rc = make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A);

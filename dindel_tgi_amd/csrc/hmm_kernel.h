@@ -46,6 +46,7 @@ struct KernelArgs {
     dd_result out;
     /* params */
     int32_t D, maxLengthDel, padCover, bMid;
+    int32_t always_ro;                   /* 1: never skip the RO sink chain speculatively (diagnostics / A-B) */
     /* launch geometry */
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
     int32_t item_begin;                  /* this launch covers items [item_begin, n_items) (chunked host path) */

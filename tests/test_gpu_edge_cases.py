@@ -181,3 +181,20 @@ def test_long_reads_config5_shape(lib):
         hap = rnd(hs)
         haps = [hap, hap[:hs // 2] + hap[hs // 2 + 3:], hap[:hs // 2] + "ACG" + hap[hs // 2:]]
         check(lib, [Window(1000, haps, reads_from(hap, 6, 250) + reads_from(haps[1], 6, 250))], p)
+
+
+def test_low_likelihood_pairs_redo_with_ro_chain(lib):
+    """Pairs whose best log-likelihood is below -99 cannot use the speculative pass that leaves the RO sink chain
+    out (kernel comment at the Dec loop): long, very low quality reads force the redo path; results stay bit-equal."""
+    hap = rnd(120)
+    reads = []
+    for i in range(10):
+        L = 250
+        off = int(RNG.integers(-100, 100))
+        seq = "".join(hap[j] if 0 <= j < len(hap) else RNG.choice(list("ACGT")) for j in range(off, off + L))
+        q = phred_to_prob([2 + (i % 3)])[0]
+        reads.append(ReadRec(mutate(seq, 0.2), [q] * L, [1 - 1e-16, 0.5, 0.999999][i % 3], 1000 + off))
+    reads += reads_from(hap, 4, 100)                      # ordinary pairs in the same batch take the fast pass
+    pb, got = check(lib, [Window(1000, [hap, hap[:60] + hap[64:]], reads)])
+    assert (got["ll"][:pb.n_pairs] < -99).sum() >= 10 and (got["ll"][:pb.n_pairs] > -99).sum() >= 4
+    check(lib, [Window(1000, [hap], reads)], capi.params_struct_defaults())
