@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
     typedef BtPack<K, D> BP;
     typedef typename BtWord<BP::BYTES>::type btword_t;
+    typedef typename BtWord<(BP::BYTES == 8 ? 8 : 4)>::type btacc_t;   // register type the word is assembled in
     btword_t *bt;                                                          // [Lmax][64] packed back-pointers
     if constexpr (GBT)
         bt = reinterpret_cast<btword_t *>(P.bt_scratch) + (size_t)(blockIdx.x * nwav + wave) * (size_t)P.bt_rows * 64;
@@ -354,30 +355,31 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                     ov[K + j] = t.y;
                 }
                 double na[K], ni[K];
-                unsigned btb[K];
+                btacc_t btb[K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     double best = (cInc[k][0] + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
-                    unsigned ch = 1;
+                    const int sh = k * BP::PB;
+                    btacc_t ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
                         const double val = (cInc[k][y - 1] + v[k + y]) + ov[k + y];
                         const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
                         best = take ? val : best;
-                        ch = take ? (unsigned)y : ch;
+                        ch = take ? ((btacc_t)y << sh) : ch;
                     }
                     {
                         const double val = (eq + in[k]) + eInc[k]; // to inserted state numS+x (:1746-1749)
                         const bool take = val > best + DD_EPS;
                         best = take ? val : best;
-                        ch = take ? 0u : ch;
+                        ch = take ? (btacc_t)0 : ch;
                     }
                     na[k] = best;
                     const double d = (eq + in[k]) + II;            // (:1754-1758)
                     const double val = (ov[k + 1] + v[k + 1]) + NI;   // src = x+1 (:1763-1767)
                     const bool take = val >= d;
                     ni[k] = dmax(d, val);
-                    btb[k] = ch | (take ? (1u << BP::CB) : 0u);
+                    btb[k] = ch | (take ? ((btacc_t)(1u << BP::CB) << sh) : (btacc_t)0);
                 }
                 if (lane == 0) {                                    // x = 0 (:1720-1722, :1746-1749, :1762)
                     double best = ((eq + a[0]) + lLL) + NN;         // idx 0
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                     const double val = (eq + a[0]) + NI;
                     const bool take = val >= d;
                     ni[0] = dmax(d, val);
-                    btb[0] = code | (take ? (1u << BP::CB) : 0u);
+                    btb[0] = (btacc_t)(code | (take ? (1u << BP::CB) : 0u));
                 }
                 if (lane == laneRO) {                               // x = RO (:1741-1742, :1750, :1763-1767)
 #pragma unroll
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                             const double val = (eq + a[k]) + NI;
                             const bool take = val >= d;
                             ni[k] = dmax(d, val);
-                            btb[k] = (t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u);
+                            btb[k] = (btacc_t)((t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u)) << (k * BP::PB);
                         }
                     }
                 }
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    word |= (btword_t)((btword_t)btb[k] << (k * BP::PB));
+                    word |= (btword_t)btb[k];
                 }
                 bt[b * 64 + lane] = word;                           // btb[b-1] stored at row b
             }
@@ -475,31 +477,32 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 }
                 const double im1 = rowI[x0];                        // I[x0-1]
                 double na[K], ni[K];
-                unsigned btb[K];
+                btacc_t btb[K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     double best = ((ov[D + k - 1] + lpDec[k][0]) + v[D + k - 1]) + lpn[k];    // (:1793), y = 1
-                    unsigned ch = 1;
+                    const int sh = k * BP::PB;                    // this position's field in the packed word
+                    btacc_t ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
                         const double val = ((ov[D + k - y] + lpDec[k][y - 1]) + v[D + k - y]) + lpn[k];
                         const bool take = val >= best;             // newIdx < destIdx: either branch of updateMax
                         best = dmax(best, val);
-                        ch = take ? (unsigned)y : ch;
+                        ch = take ? ((btacc_t)y << sh) : ch;
                     }
                     {
                         const double ip = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
                         const double val = (eq + ip) + eIn[k];     // from inserted state numS+x-1 (:1807-1811)
                         const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
                         best = take ? val : best;
-                        ch = take ? 0u : ch;
+                        ch = take ? (btacc_t)0 : ch;
                     }
                     na[k] = best;
                     const double d = (eq + in[k]) + II;            // stay inserted (:1816-1820)
                     const double val = (ov[D + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
                     const bool take = val >= d;
                     ni[k] = dmax(d, val);
-                    btb[k] = ch | (take ? (1u << BP::CB) : 0u);
+                    btb[k] = ch | (take ? ((btacc_t)(1u << BP::CB) << sh) : (btacc_t)0);
                 }
                 if (lane == 0) {                                    // x = 0 (:1798-1799)
                     na[0] = (eq + a[0]) + NN;
@@ -527,7 +530,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                             best = t4 ? c4 : best;
                             code = t4 ? 3u : code;
                             na[k] = best;
-                            btb[k] = (btb[k] & (1u << BP::CB)) | code;
+                            btb[k] = (btb[k] & ((btacc_t)(1u << BP::CB) << (k * BP::PB))) | ((btacc_t)code << (k * BP::PB));
                         }
                     }
                 }
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    word |= (btword_t)((btword_t)btb[k] << (k * BP::PB));
+                    word |= (btword_t)btb[k];
                 }
                 bt[b * 64 + lane] = word;
             }
