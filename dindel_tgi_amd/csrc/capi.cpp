@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -349,8 +350,17 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
 
 // Enqueue the path for haplotypes [hap_begin, hap_end) and reads [read_begin, read_end) of the batch (a
 // contiguous block of windows); hap_end < 0 means the whole batch.
+// One (haplotype-length class, read-length class) of a ragged batch: the launch plan (K, LDS tile) is made for
+// the class' own maxima instead of the batch-wide ones.
+struct LenClass {
+    const int32_t *hap_list = nullptr;   // device: haplotype indices of the class (sorted); nullptr = all haplotypes
+    int list_begin = 0, list_end = 0;    // range of hap_list this launch covers
+    int max_hap_len = 0, max_read_len = 0, min_read_len = 1;
+    bool run_onhap = true;
+};
+
 static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes,
-                        void *stream, int hap_begin, int hap_end, int read_begin, int read_end)
+                        void *stream, int hap_begin, int hap_end, int read_begin, int read_end, const LenClass *lc = nullptr)
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -375,15 +385,19 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     A.always_ro = getenv("DD_ALWAYS_RO") ? 1 : 0;
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
     Plan pl;
-    rc = make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A);
+    const int cls_hap = lc ? lc->max_hap_len : b->max_hap_len, cls_read = lc ? lc->max_read_len : b->max_read_len;
+    rc = make_plan(p, cls_hap, cls_read, b->n_qual, pl, A);
     if (rc) return rc;
+    A.hap_list = lc ? lc->hap_list : nullptr;
+    A.len_min = lc ? lc->min_read_len : 0;
+    A.len_max = lc ? lc->max_read_len : 0x7fffffff;
     const int K = pl.K, Dt = pl.Dt, waves = pl.waves;
     const size_t lds = pl.lds;
     if (pl.gbt) {
         if (!workspace || workspace_bytes < pl.scratch_bytes)
             return fail(DD_ERR_INVALID, "workspace too small for this shape: allocate dd_workspace_bytes() bytes");
         A.bt_scratch = workspace;
-        A.bt_rows = b->max_read_len;
+        A.bt_rows = cls_read;
     }
     // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
     const int64_t target_blocks = 4096;
@@ -395,19 +409,23 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     if (split < 1) split = 1;
     A.n_split = (int32_t)split;
     if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
+    if (lc && lc->hap_list) { hap_begin = lc->list_begin; hap_end = lc->list_end; }   // positions in the class list
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.item_begin = (int32_t)(hap_begin * split);
     A.n_items = (int32_t)(hap_end * split);
     A.read_begin = read_begin; A.read_end = read_end;
     int64_t grid = (int64_t)(hap_end - hap_begin) * split;
-    if (grid <= 0) return DD_SUCCESS;
+    if (grid <= 0) {
+        if (r->onHap && r->offHapHMQ && lc && lc->run_onhap) HIP_TRY(ddk::launch_onhap(A, static_cast<hipStream_t>(stream)));
+        return DD_SUCCESS;
+    }
     if (pl.grid_cap && grid > pl.grid_cap) grid = pl.grid_cap;
     g_last_launch[0] = K; g_last_launch[1] = Dt + (pl.gbt ? 100 : 0); g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, A, (unsigned)grid, waves, lds, st));
-    if (r->onHap && r->offHapHMQ) HIP_TRY(ddk::launch_onhap(A, st));
+    if (r->onHap && r->offHapHMQ && (!lc || lc->run_onhap)) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
 }
 
@@ -563,7 +581,56 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     // of block c is issued after the kernel of block c+1 has been enqueued, so the copy engine drains results
     // while the CUs work on the next block (with pageable user memory the copy call blocks the host thread, not
     // the GPU).  Each stream has its own back-pointer scratch.
-    const size_t ws_bytes = dd_workspace_bytes(p, &db);
+    // Ragged batches: haplotypes are grouped by the lane tiling they need (K) and reads by length class, and each
+    // non-empty (K class, length class) gets its own launches — a single 170-bp haplotype or 250-bp read no longer
+    // drags every pair of the batch onto the K=3 / long-read build.
+    static const int kHapBounds[] = {62, 126, 190, 254, 382, 510, DD_MAX_HAP_LEN};          // 64*K - 2
+    // reads: one class up to 160 bp (LDS back-pointer tile still leaves >= 8 waves per CU), one for longer reads
+    // (HBM-scratch build).  Finer read classes cost more in repeated per-haplotype setup than they gain
+    // (tools/ragged_bench.py: 5000 ragged windows 0.2125 s with haplotype classes only, 0.2532 s with five read classes,
+    // 0.2455 s with one batch-wide plan).
+    static const int kReadBounds[] = {160, DD_MAX_READ_LEN};
+    struct HostClass { std::vector<int32_t> haps; int max_hap = 0; const int32_t *dev = nullptr; };
+    std::vector<HostClass> hcls(sizeof(kHapBounds) / sizeof(int));
+    for (int64_t h = 0; h < sz.n_haps; h++) {
+        const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+        size_t c = 0;
+        while (len > kHapBounds[c]) c++;
+        hcls[c].haps.push_back((int32_t)h);
+        if (len > hcls[c].max_hap) hcls[c].max_hap = len;
+    }
+    struct ReadClass { int lo, hi, max_len; };
+    std::vector<ReadClass> rcls;
+    {
+        int lo = 1;
+        for (int bound : kReadBounds) {
+            int mx = 0;
+            for (int64_t q = 0; q < sz.n_reads; q++) {
+                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+                if (len >= lo && len <= bound && len > mx) mx = len;
+            }
+            if (mx) rcls.push_back({lo, bound, mx});
+            lo = bound + 1;
+        }
+        if (getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k") && !rcls.empty()) {
+            ReadClass all = {1, DD_MAX_READ_LEN, rcls.back().max_len};      // A/B: haplotype classes only
+            rcls.assign(1, all);
+        }
+    }
+    size_t ws_bytes = dd_workspace_bytes(p, &db);
+    int n_classes = 0;
+    for (auto &hc : hcls) {
+        if (hc.haps.empty()) continue;
+        n_classes++;
+        if ((rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;
+        for (auto &rcl : rcls) {
+            dd_device_batch tmp = db;
+            tmp.max_hap_len = hc.max_hap; tmp.max_read_len = rcl.max_len;
+            const size_t w = dd_workspace_bytes(p, &tmp);
+            if (w > ws_bytes) ws_bytes = w;
+        }
+    }
+    const bool single_class = (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
     unsigned char *ws[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++)
         if (ws_bytes && (rc = dev.alloc(&ws[i], ws_bytes))) return rc;
@@ -601,9 +668,29 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     };
     for (int c = 0; c < n_chunks; c++) {
         const int w0 = cw[c], w1 = cw[c + 1];
-        rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], b->win_hap_off[w0], b->win_hap_off[w1],
-                          b->win_read_off[w0], b->win_read_off[w1]);
-        if (rc) return rc;
+        const int g0 = b->win_hap_off[w0], g1 = b->win_hap_off[w1], q0 = b->win_read_off[w0], q1 = b->win_read_off[w1];
+        if (single_class) {
+            rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1);
+            if (rc) return rc;
+        } else {
+            // every (K class, length class) of this window block, then onHap once
+            int launched = 0, total = 0;
+            for (auto &hc : hcls) if (!hc.haps.empty()) total += (int)rcls.size();
+            for (auto &hc : hcls) {
+                if (hc.haps.empty()) continue;
+                LenClass lc;
+                lc.hap_list = hc.dev;
+                lc.list_begin = (int)(std::lower_bound(hc.haps.begin(), hc.haps.end(), g0) - hc.haps.begin());
+                lc.list_end = (int)(std::lower_bound(hc.haps.begin(), hc.haps.end(), g1) - hc.haps.begin());
+                lc.max_hap_len = hc.max_hap;
+                for (auto &rcl : rcls) {
+                    lc.min_read_len = rcl.lo; lc.max_read_len = rcl.max_len;
+                    lc.run_onhap = (++launched == total);
+                    rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
+                    if (rc) return rc;
+                }
+            }
+        }
         if (c > 0 && (rc = download(c - 1))) return rc;
     }
     if ((rc = download(n_chunks - 1))) return rc;

@@ -51,6 +51,9 @@ struct KernelArgs {
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
     int32_t item_begin;                  /* this launch covers items [item_begin, n_items) (chunked host path) */
     int32_t read_begin, read_end;        /* reads covered by this launch (onHap kernel) */
+    const int32_t *hap_list;             /* length-class launches: haplotype of item i is hap_list[i / n_split]; NULL = identity */
+    int32_t len_min, len_max;            /* length-class launches: only reads with len_min <= L <= len_max */
+    int32_t run_onhap;
     void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */

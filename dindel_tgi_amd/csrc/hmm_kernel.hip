@@ -194,8 +194,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     // ======================= loop over this workgroup's (haplotype, read-slice) items =======================
     for (int item = P.item_begin + blockIdx.x; item < P.n_items; item += gridDim.x) {
     __syncthreads();                               // every wave is done with the previous haplotype's LDS tables
-    const int g = item / P.n_split;                // global haplotype index
-    const int split = item - g * P.n_split;
+    const int gi = item / P.n_split;
+    const int split = item - gi * P.n_split;
+    const int g = P.hap_list ? P.hap_list[gi] : gi;   // global haplotype index
 
     const int w = P.hap_window[g];
     const int h0 = P.win_hap_off[w];
@@ -277,6 +278,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         const int so = P.read_seq_off[r];
         const int L = P.read_seq_off[r + 1] - so;
 
+        if (L < P.len_min || L > P.len_max) continue;      // another length-class launch owns this read
         if (!hap_ok) {
             if (lane == 0) {
                 P.out.status[pair] = DD_PAIR_HAPSIZE;

@@ -198,3 +198,23 @@ def test_low_likelihood_pairs_redo_with_ro_chain(lib):
     pb, got = check(lib, [Window(1000, [hap, hap[:60] + hap[64:]], reads)])
     assert (got["ll"][:pb.n_pairs] < -99).sum() >= 10 and (got["ll"][:pb.n_pairs] > -99).sum() >= 4
     check(lib, [Window(1000, [hap], reads)], capi.params_struct_defaults())
+
+
+def test_mixed_length_classes_in_one_batch(lib):
+    """A ragged batch spanning several haplotype-length (K) classes and read-length classes, including one that
+    needs the HBM-scratch build: the host path launches every class separately; results equal the oracle's and
+    equal a one-class-at-a-time evaluation."""
+    ws = []
+    for hs, Ls in ((50, (30, 64, 65)), (120, (100, 36, 150)), (170, (100, 250)), (130, (128, 129)), (400, (600, 90)), (4, (20,))):
+        hap = rnd(hs)
+        var = hap[:hs // 2] + hap[hs // 2 + 1:] if hs > 10 else hap
+        reads = []
+        for L in Ls:
+            reads += reads_from(hap, 3, L, junk=0.0)
+        ws.append(Window(1000, [hap, var], reads))
+    # one window mixing short and long haplotypes (candidate injection can do this) and all read lengths
+    hap = rnd(125)
+    ws.append(Window(1000, [hap, hap + rnd(60), hap[:60]], reads_from(hap, 4, 40) + reads_from(hap, 4, 100) + reads_from(hap, 2, 300)))
+    pb, got = check(lib, ws)
+    st = got["status"][:pb.n_pairs]
+    assert (st == capi.DD_PAIR_HAPSIZE).sum() == 2 * 3          # the 4-bp haplotypes (maxLengthDel = 5), every read once
