@@ -69,7 +69,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
     A.n_qual = n_qual;
     A.lds_shared_bytes = o;
     uint32_t wv = 0;
-    A.lds_off_A = wv;   wv += up16((2 * Dt + NP) * 16);   // {value, emission} per state + pads
+    A.lds_off_A = wv;   wv += up16((uint32_t)K * (64u + 2u * (uint32_t)((Dt + K - 1) / K)) * 16u);   // K arrays of {value, emission} + pads
     A.lds_off_I = wv;   wv += up16((NP + 2) * 8);
     A.lds_off_rdE = wv; wv += up16(Lmax * 16);
     A.lds_off_rdC = wv; wv += up16(Lmax);

@@ -170,7 +170,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     // ---------------- wave-private region ----------------
     unsigned char *wbase = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
     // one HMM slice as the neighbours see it: {value, emission log of that state for the slice's read base}
-    double2 *rowA = reinterpret_cast<double2 *>(wbase + P.lds_off_A);     // [D + NP + D]   state s -> rowA[D+s]
+    // K interleaved arrays (state s lives in array s % K at index s / K, PADQ pad entries either side) so that every
+    // wave-wide ds_read_b128 / ds_write_b128 touches consecutive 16-byte slots: a flat [state] layout puts lanes l and
+    // l+8 on the same banks for K = 2 (2-way conflict on every neighbour read; SQ_LDS_BANK_CONFLICT was 41 % of LDS cycles)
+    constexpr int PADQ = (D + K - 1) / K;
+    constexpr int AQ = 64 + 2 * PADQ;
+    double2 *rowA = reinterpret_cast<double2 *>(wbase + P.lds_off_A);     // [K][AQ]
     double *rowI = reinterpret_cast<double *>(wbase + P.lds_off_I);       // [1 + NP + 1]   state s -> rowI[1+s]
     double *rdE = reinterpret_cast<double *>(wbase + P.lds_off_rdE);      // [Lmax][2]  eq, uq per read base
     unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
@@ -187,7 +192,6 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
 
     for (int i = tid; i < 4 * P.n_qual; i += nthr) shQ[i] = T[T_QUAL + i];
     // pads of the wave-private rows: written once, never touched again
-    if (lane < D) { rowA[lane] = make_double2(NEG_INF, 0.0); rowA[D + NP + lane] = make_double2(NEG_INF, 0.0); }
     if (lane == 0) { rowI[0] = NEG_INF; rowI[1 + NP] = NEG_INF; }
     STAMP_INIT;
 
@@ -317,6 +321,11 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        // pads of the slice arrays (the join's near-tie replay may have used the buffer as scratch)
+        for (int i = lane; i < 2 * PADQ * K; i += 64) {
+            const int kk = i / (2 * PADQ), j = i - kk * (2 * PADQ);
+            rowA[kk * AQ + (j < PADQ ? j : 64 + j)] = make_double2(NEG_INF, 0.0);
+        }
         STAMP(1);   // bMid + staging
         double a[K], in[K];           // current slice: "on base x" and "inserted at x"
         // ================= right -> middle: passMessageTwoInc for b = L-1..bMid+1 (:1576-1578, :1715-1773)
@@ -346,13 +355,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     ov[k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
                     v[k] = a[k];
-                    rowA[D + x0 + k] = make_double2(a[k], ov[k]);
+                    rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[k]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int j = 0; j < D; j++) {                      // states x0+K .. x0+K+D-1
-                    const double2 t = rowA[D + x0 + K + j];
+                    const double2 t = rowA[((K + j) % K) * AQ + PADQ + lane + (K + j) / K];   // state x0+K+j
                     v[K + j] = t.x;
                     ov[K + j] = t.y;
                 }
@@ -466,14 +475,15 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     ov[D + k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
                     v[D + k] = a[k];
-                    rowA[D + x0 + k] = make_double2(a[k], ov[D + k]);
+                    rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[D + k]);
                     rowI[1 + x0 + k] = in[k];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int j = 0; j < D; j++) {                      // states x0-D .. x0-1
-                    const double2 t = rowA[x0 + j];
+                    const int off = j - D, kk = ((off % K) + K) % K, q = (off - kk) / K;      // state x0-D+j = (lane+q)*K + kk
+                    const double2 t = rowA[kk * AQ + PADQ + lane + q];
                     v[j] = t.x;
                     ov[j] = t.y;
                 }
@@ -557,7 +567,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             const double hqOff0 = T[TC_HMQ + 0], hqOff1 = T[TC_HMQ + 1], hqOn0 = T[TC_HMQ + 2], hqOn1 = T[TC_HMQ + 3];
             const double roPrior = with_ro ? -100.0 : NEG_INF;     // prior[RO] = -100 (:299); -inf while RO is not evaluated
             double vA[K], vI[K], hA[K], hI[K];
-            double *scanA = reinterpret_cast<double *>(rowA + D), *scanI = scanA + NP;   // near-tie replay scratch (row is free now)
+            double *scanA = reinterpret_cast<double *>(rowA), *scanI = scanA + NP;   // near-tie replay scratch (the slice buffer is free now)
             double on = NEG_INF;
 #pragma unroll
             for (int k = 0; k < K; k++) {
