@@ -67,6 +67,11 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
     A.lds_off_N = o;  o += up16((NP + Dt + 2) * 8);
     A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
     A.n_qual = n_qual;
+    A.lds_off_C = o;  A.lds_off_Y = o;
+    if (gbt && Dt == 11) {                       // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
+        o += up16((uint32_t)K * Dt * 64u * 8u);
+        A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
+    }
     A.lds_shared_bytes = o;
     uint32_t wv = 0;
     A.lds_off_A = wv;   wv += up16((uint32_t)K * (64u + 2u * (uint32_t)((Dt + K - 1) / K)) * 16u);   // K arrays of {value, emission} + pads
@@ -108,9 +113,10 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     pl.K = pick_K(max_hap_len);
     pl.Dt = pick_Dt(p->maxLengthDel + 1);
     if (pl.K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
-    int best[2] = {0, 0}, bw[2] = {0, 0};
+    int best[2] = {0, 0}, bw[2] = {0, 0}, cap[2] = {0, 0};
     for (int gbt = 0; gbt < 2; gbt++) {
         const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0);
+        cap[gbt] = reg_cap;
         for (int wv = DD_WAVES; wv >= 1; wv--) {
             ddk::KernelArgs tmp = A;
             const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, gbt != 0, tmp);
@@ -122,13 +128,15 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     }
     if (best[0] == 0 && best[1] == 0)
         return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length does not fit the LDS row buffers");
-    // HBM scratch costs a dependent global load per traceback step: use it only where LDS would leave the CU
-    // clearly emptier than the registers allow (measured: 8 of 12 waves -> LDS still wins by 19 %; 6 of 12 ->
-    // scratch wins by 26 %; tools/stress_sweep.py)
-    pl.gbt = best[0] == 0 || 3 * best[0] < 2 * best[1];
-#ifdef DD_FORCE_GBT
-    pl.gbt = DD_FORCE_GBT != 0 && best[1] > 0;
-#endif
+    // HBM scratch costs a coalesced row fetch per 8 traceback steps and (D=11) block-shared constants; the LDS tile
+    // costs occupancy.  Measured over six shapes (tools/ab_point.py with DD_FORCE_GBT=0/1): the LDS build wins
+    // whenever its tile still lets the CU hold as many waves as its registers allow, the scratch build wins
+    // (5-80 %) once LDS caps it at <= 3/4 of that.
+    pl.gbt = best[0] == 0 || 4 * best[0] <= 3 * cap[0];
+    if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
+        if (f[0] == '1' && best[1] > 0) pl.gbt = true;
+        if (f[0] == '0' && best[0] > 0) pl.gbt = false;
+    }
     pl.waves = bw[pl.gbt ? 1 : 0];
     pl.waves_per_cu = best[pl.gbt ? 1 : 0];
     pl.lds = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, pl.waves, pl.gbt, A);

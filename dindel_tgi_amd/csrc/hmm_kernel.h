@@ -57,7 +57,7 @@ struct KernelArgs {
     void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */
-    uint32_t lds_off_E, lds_off_N, lds_off_Q, lds_shared_bytes, lds_wave_bytes;
+    uint32_t lds_off_E, lds_off_N, lds_off_Q, lds_off_C, lds_off_Y, lds_shared_bytes, lds_wave_bytes;
     int32_t n_qual;
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
 };

@@ -181,6 +181,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
     unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
+    // LEAN (HBM-scratch build at D = 11): the two [K][D] per-lane constant arrays (88 VGPRs at K = 2) do not fit next
+    // to the slice window at 3 waves/SIMD; the Inc constants come from a block-shared LDS table instead (LDS is idle in
+    // this build) and the Dec jump penalties are formed on the fly from E[x] and a broadcast (y-1)*II.
+    constexpr bool LEAN = GBT && (D == 11);
+    double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][64] lp_y(src)+Nn[src]
+    double *shY = reinterpret_cast<double *>(smem + P.lds_off_Y);  // LEAN: [D] (y-1)*II
     typedef BtPack<K, D> BP;
     typedef typename BtWord<BP::BYTES>::type btword_t;
     typedef typename BtWord<(BP::BYTES == 8 ? 8 : 4)>::type btacc_t;   // register type the word is assembled in
@@ -247,6 +253,21 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     }
     __syncthreads();
 
+    if constexpr (LEAN) {
+        for (int i = tid; i < K * D * 64; i += nthr) {
+            const int l = i & 63, ky = i >> 6, k = ky / D, y = ky - k * D + 1;
+            const int src = l * K + k + y;
+            double c = NEG_INF;
+            if (src <= RO && y <= Dr) {
+                const double Es = shE[src], Ns = shN[src];
+                const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
+                c = lp + Ns;
+            }
+            shC[i] = c;
+        }
+        for (int i = tid; i < D; i += nthr) shY[i] = (double)i * II;
+        __syncthreads();
+    }
     // ---- per-lane register constants for this haplotype (states past RO are switched off with -inf) ----
     const int x0 = lane * K;
     const int laneRO = RO / K, kRO = RO - laneRO * K;
@@ -336,17 +357,22 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             in[k] = valid ? 0.0 : NEG_INF;
         }
         {
-            double cInc[K][D];                 // lp_y(src)+Nn[src] for src = x+y  (:1730-1735)
+            double cInc[LEAN ? 1 : K][LEAN ? 1 : D];   // lp_y(src)+Nn[src] for src = x+y  (:1730-1735)
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
+                for (int k = 0; k < K; k++) {
 #pragma unroll
-                for (int y = 1; y <= D; y++) {
-                    const int src = x0 + k + y;
-                    const double Es = shE[src], Ns = shN[src];
-                    const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
-                    cInc[k][y - 1] = (src <= RO && y <= Dr) ? lp + Ns : NEG_INF;
+                    for (int y = 1; y <= D; y++) {
+                        const int src = x0 + k + y;
+                        const double Es = shE[src], Ns = shN[src];
+                        const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
+                        cInc[k][y - 1] = (src <= RO && y <= Dr) ? lp + Ns : NEG_INF;
+                    }
                 }
             }
+            auto cinc = [&](int k, int y) -> double {       // y = 1..D
+                if constexpr (LEAN) return shC[(k * D + y - 1) * 64 + lane]; else return cInc[k][y - 1];
+            };
             for (int b = L - 1; b > bMid; b--) {
                 const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
                 const int col = rdC[b] > 4 ? 4 : rdC[b];
@@ -369,12 +395,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 btacc_t btb[K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    double best = (cInc[k][0] + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
-                    const int sh = k * BP::PB;
+                    double best = (cinc(k, 1) + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
+                    const int sh = (D <= 7) ? k * BP::PB : 0;
                     btacc_t ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
-                        const double val = (cInc[k][y - 1] + v[k + y]) + ov[k + y];
+                        const double val = (cinc(k, y) + v[k + y]) + ov[k + y];
                         const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
                         best = take ? val : best;
                         ch = take ? ((btacc_t)y << sh) : ch;
@@ -423,7 +449,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                             const double val = (eq + a[k]) + NI;
                             const bool take = val >= d;
                             ni[k] = dmax(d, val);
-                            btb[k] = (btacc_t)((t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u)) << (k * BP::PB);
+                            btb[k] = (btacc_t)((t2 ? 1u : 0u) | (take ? (1u << BP::CB) : 0u)) << ((D <= 7) ? k * BP::PB : 0);
                         }
                     }
                 }
@@ -432,7 +458,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    word |= (btword_t)btb[k];
+                    word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
                 bt[b * 64 + lane] = word;                           // btb[b-1] stored at row b
             }
@@ -459,12 +485,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             in[k] = valid ? 0.0 : NEG_INF;
         }
         {
-            double lpDec[K][D];               // y=1: Nn[x]; y>=2: E[x]+(y-1)*II   (:1786-1791)
+            double lpDec[LEAN ? 1 : K][LEAN ? 1 : D];   // y=1: Nn[x]; y>=2: E[x]+(y-1)*II   (:1786-1791)
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                lpDec[k][0] = lpn[k];
+                for (int k = 0; k < K; k++) {
+                    lpDec[k][0] = lpn[k];
 #pragma unroll
-                for (int y = 2; y <= D; y++) lpDec[k][y - 1] = (y > Dr) ? NEG_INF : eIn[k] + (double)(y - 1) * II;
+                    for (int y = 2; y <= D; y++) lpDec[k][y - 1] = (y > Dr) ? NEG_INF : eIn[k] + (double)(y - 1) * II;
+                }
             }
             for (int b = 1; b <= bMid; b++) {
                 const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
@@ -492,12 +520,15 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 btacc_t btb[K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    double best = ((ov[D + k - 1] + lpDec[k][0]) + v[D + k - 1]) + lpn[k];    // (:1793), y = 1
-                    const int sh = k * BP::PB;                    // this position's field in the packed word
+                    double best = ((ov[D + k - 1] + lpn[k]) + v[D + k - 1]) + lpn[k];         // (:1793), y = 1: lp = lpn
+                    const int sh = (D <= 7) ? k * BP::PB : 0;     // field of this position in the packed word (D<=7: codes are
+                                                                  // pre-shifted; larger codes would stop being inline constants)
                     btacc_t ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
-                        const double val = ((ov[D + k - y] + lpDec[k][y - 1]) + v[D + k - y]) + lpn[k];
+                        double lp;
+                        if constexpr (LEAN) lp = eIn[k] + shY[y - 1]; else lp = lpDec[k][y - 1];
+                        const double val = ((ov[D + k - y] + lp) + v[D + k - y]) + lpn[k];
                         const bool take = val >= best;             // newIdx < destIdx: either branch of updateMax
                         best = dmax(best, val);
                         ch = take ? ((btacc_t)y << sh) : ch;
@@ -542,7 +573,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                             best = t4 ? c4 : best;
                             code = t4 ? 3u : code;
                             na[k] = best;
-                            btb[k] = (btb[k] & ((btacc_t)(1u << BP::CB) << (k * BP::PB))) | ((btacc_t)code << (k * BP::PB));
+                            btb[k] = (btb[k] & ((btacc_t)(1u << BP::CB) << ((D <= 7) ? k * BP::PB : 0))) | ((btacc_t)code << ((D <= 7) ? k * BP::PB : 0));
                         }
                     }
                 }
@@ -551,7 +582,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 for (int k = 0; k < K; k++) {
                     a[k] = na[k];
                     in[k] = ni[k];
-                    word |= (btword_t)btb[k];
+                    word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
                 bt[b * 64 + lane] = word;
             }
