@@ -633,10 +633,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (GBT) {
-            // the tile was written by all 64 lanes and is now read through another lane's address: make the
-            // stores visible at L2 and drop this CU's L1 copies of the tile (possibly stale from the previous read)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // The tile was written by all 64 lanes and is now read through another lane's address — by the SAME wave on
+            // the same CU.  Workgroup scope is enough (the CU's vector L1 is write-through and coherent for its own
+            // stores); it waits for the stores (vmcnt) without the L2 write-back an agent-scope release costs on a
+            // multi-XCD part.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         {
             // the chain is wave-uniform: keep it on the scalar unit (readfirstlane) so the ~L dependent steps
