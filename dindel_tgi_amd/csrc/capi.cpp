@@ -68,7 +68,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
     A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
     A.n_qual = n_qual;
     A.lds_off_C = o;  A.lds_off_Y = o;
-    if (gbt && Dt == 11) {                       // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
+    if (gbt && (Dt > 7 || K >= 3)) {             // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
         o += up16((uint32_t)K * Dt * 64u * 8u);
         A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
     }
@@ -91,7 +91,13 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
 }
 
 // waves per CU the register file allows for each K (kernel-resource-usage of the shipped builds)
-int reg_limited_waves_per_cu(int K, int Dt, bool gbt) { return K <= 2 ? ((Dt <= 7 || gbt) ? 12 : 8) : K == 3 ? (Dt <= 7 ? 8 : 4) : 4; }
+int reg_limited_waves_per_cu(int K, int Dt, bool gbt)
+{
+    if (K <= 2) return (Dt <= 7 || gbt) ? 12 : 8;
+    if (K == 3) return (gbt || Dt <= 7) ? 8 : 4;
+    if (K == 4) return gbt ? 8 : 4;
+    return 4;
+}
 
 uint32_t bt_word_bytes(int K, int Dt)
 {
@@ -132,7 +138,9 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     // costs occupancy.  Measured over six shapes (tools/ab_point.py with DD_FORCE_GBT=0/1): the LDS build wins
     // whenever its tile still lets the CU hold as many waves as its registers allow, the scratch build wins
     // (5-80 %) once LDS caps it at <= 3/4 of that.
-    pl.gbt = best[0] == 0 || 4 * best[0] <= 3 * cap[0];
+    // For K >= 3 the scratch build is also the register-lean one (block-shared constants) and wins at every
+    // shape measured (+26 ... +41 %).
+    pl.gbt = best[0] == 0 || (pl.K >= 3 && best[1] > 0) || 4 * best[0] <= 3 * cap[0];
     if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
         if (f[0] == '1' && best[1] > 0) pl.gbt = true;
         if (f[0] == '0' && best[0] > 0) pl.gbt = false;

@@ -141,7 +141,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // needs ~236 VGPRs unspilled: the HBM-scratch build still gains 14 % at 3 waves with spills, the LDS build is
 // LDS-limited to 2 waves/SIMD anyway and loses 7 % to the spills, so it stays at 2.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : 1)
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : (((K) <= 4 && (GBT)) ? 2 : 1))
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
@@ -181,10 +181,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     unsigned char *rdC = wbase + P.lds_off_rdC;                            // [Lmax] read base code 0..5
     unsigned char *rdQ = wbase + P.lds_off_rdQ;                            // [Lmax] quality index
     int16_t *ms = reinterpret_cast<int16_t *>(wbase + P.lds_off_ms);      // [Lmax] MAP state per base
-    // LEAN (HBM-scratch build at D = 11): the two [K][D] per-lane constant arrays (88 VGPRs at K = 2) do not fit next
+    // LEAN (HBM-scratch builds with D > 7 or K >= 3): the two [K][D] per-lane constant arrays (88 VGPRs at K = 2, D = 11) do not fit next
     // to the slice window at 3 waves/SIMD; the Inc constants come from a block-shared LDS table instead (LDS is idle in
     // this build) and the Dec jump penalties are formed on the fly from E[x] and a broadcast (y-1)*II.
-    constexpr bool LEAN = GBT && (D == 11);
+    constexpr bool LEAN = GBT && (D > 7 || K >= 3);
     double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][64] lp_y(src)+Nn[src]
     double *shY = reinterpret_cast<double *>(smem + P.lds_off_Y);  // LEAN: [D] (y-1)*II
     typedef BtPack<K, D> BP;
