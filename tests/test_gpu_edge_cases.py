@@ -218,3 +218,17 @@ def test_mixed_length_classes_in_one_batch(lib):
     pb, got = check(lib, ws)
     st = got["status"][:pb.n_pairs]
     assert (st == capi.DD_PAIR_HAPSIZE).sum() == 2 * 3          # the 4-bp haplotypes (maxLengthDel = 5), every read once
+
+
+def test_hbm_scratch_tile_reuse_many_reads_per_wave(lib):
+    """HBM-scratch build under tile reuse: every wave walks many reads of different lengths through the same scratch
+    tile (stale-cache hazards would corrupt the traceback of later reads)."""
+    p = capi.params_cli_defaults()
+    p.maxLengthDel = 10
+    hap = rnd(125)
+    haps = [hap, hap[:60] + hap[66:], hap[:70] + "ACGTT" + hap[70:]]
+    reads = []
+    for L in (250, 180, 251, 200, 170, 233):
+        reads += reads_from(hap, 12, L, junk=0.05) + reads_from(haps[1], 10, L, junk=0.0)
+    pb, got = check(lib, [Window(1000, haps, reads), Window(5000, haps[::-1], reads[::-1])], p)
+    assert capi.last_launch()["D"] >= 100
