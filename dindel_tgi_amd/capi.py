@@ -97,7 +97,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
-           "dd_compute_likelihoods", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_release_cache", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -127,6 +127,7 @@ def load():
     lib.dd_batch_sizes.argtypes = [C.POINTER(dd_batch), C.POINTER(dd_sizes)]
     lib.dd_batch_offsets.argtypes = [C.POINTER(dd_batch), c_i64p, c_i64p, c_i64p]
     lib.dd_compute_likelihoods.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
+    lib.dd_release_cache.restype = None
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]

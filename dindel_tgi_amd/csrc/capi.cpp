@@ -168,16 +168,66 @@ int check_params(const dd_params *p)
     return DD_SUCCESS;
 }
 
+// Per-host-thread cache kept between calls of the host-pointer entry points: one device arena, a pinned host
+// mirror for small batches and two streams.  The literal drop-in use (one window per call) is dominated by
+// allocation / copy-call overheads otherwise (1.5 ms per call with ~30 hipMalloc + ~35 hipMemcpy).
+struct DeviceCtx {
+    int device = -1;
+    unsigned char *arena = nullptr;  size_t arena_cap = 0;
+    unsigned char *pinned = nullptr; size_t pinned_cap = 0;
+    hipStream_t s[2] = {nullptr, nullptr};
+    void release()
+    {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (arena) (void)hipFree(arena);
+        if (pinned) (void)hipHostFree(pinned);
+        for (int i = 0; i < 2; i++) if (s[i]) (void)hipStreamDestroy(s[i]);
+        arena = pinned = nullptr; arena_cap = pinned_cap = 0; s[0] = s[1] = nullptr; device = -1;
+    }
+    int reserve(int dev, size_t dev_bytes, size_t pinned_bytes)
+    {
+        if (device != dev) { release(); device = dev; }
+        hipError_t e;
+        if (dev_bytes > arena_cap) {
+            if (arena) (void)hipFree(arena);
+            arena = nullptr; arena_cap = 0;
+            const size_t want = dev_bytes + dev_bytes / 8 + (1u << 20);
+            void *p = nullptr;
+            if ((e = hipMalloc(&p, want)) != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+            arena = static_cast<unsigned char *>(p); arena_cap = want;
+        }
+        if (pinned_bytes > pinned_cap) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr; pinned_cap = 0;
+            const size_t want = pinned_bytes + pinned_bytes / 4 + (1u << 16);
+            void *p = nullptr;
+            if ((e = hipHostMalloc(&p, want, hipHostMallocDefault)) != hipSuccess) return fail(DD_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+            pinned = static_cast<unsigned char *>(p); pinned_cap = want;
+        }
+        for (int i = 0; i < 2; i++)
+            if (!s[i] && (e = hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking)) != hipSuccess)
+                return fail(DD_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        return DD_SUCCESS;
+    }
+};
+struct CtxHolder { DeviceCtx c; ~CtxHolder() { /* process/thread exit: the HIP runtime may already be gone; leak */ } };
+thread_local CtxHolder g_ctx;
+
+// Bump allocator over the cached arena.  In `staged` mode uploads are memcpy'd into the pinned mirror at the same
+// offsets and shipped with ONE hipMemcpyAsync (flush_uploads); otherwise each upload is its own (large) copy.
 struct DevBuf {
-    std::vector<void *> ptrs;
-    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    DeviceCtx &C;
+    size_t used = 0;
+    bool staged = false;
+    explicit DevBuf(DeviceCtx &c) : C(c) {}
+    static size_t align(size_t v) { return (v + 255u) & ~size_t(255u); }
     template <class T> int alloc(T **out, size_t n)
     {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-        if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-        ptrs.push_back(p);
-        *out = static_cast<T *>(p);
+        const size_t off = align(used), bytes = (n ? n : 1) * sizeof(T);
+        if (off + bytes > C.arena_cap) return fail(DD_ERR_HIP, "internal: device arena under-sized");
+        used = off + bytes;
+        *out = reinterpret_cast<T *>(C.arena + off);
         return DD_SUCCESS;
     }
     template <class T> int upload(const T **out, const T *src, size_t n)
@@ -186,10 +236,21 @@ struct DevBuf {
         int rc = alloc(&d, n);
         if (rc) return rc;
         if (n) {
-            hipError_t e = hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+            if (staged) {
+                memcpy(C.pinned + (reinterpret_cast<unsigned char *>(d) - C.arena), src, n * sizeof(T));
+            } else {
+                hipError_t e = hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice);
+                if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+            }
         }
         *out = d;
+        return DD_SUCCESS;
+    }
+    int flush_uploads(hipStream_t st)
+    {
+        if (!staged || !used) return DD_SUCCESS;
+        hipError_t e = hipMemcpyAsync(C.arena, C.pinned, used, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(DD_ERR_HIP, std::string("hipMemcpyAsync H2D: ") + hipGetErrorString(e));
         return DD_SUCCESS;
     }
 };
@@ -212,6 +273,11 @@ const char *dd_kernel_name(void) { return "dd_hmm_kernel"; }
 void dd_last_launch(int32_t out[8])
 {   // K, D build, waves per workgroup, LDS bytes per workgroup, grid, read split, LDS per wave, shared LDS
     for (int i = 0; i < 8; i++) out[i] = g_last_launch[i];
+}
+
+void dd_release_cache(void)
+{   // frees this host thread's cached device arena, pinned mirror and streams
+    g_ctx.c.release();
 }
 
 int dd_device_count(void)
@@ -492,7 +558,9 @@ int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int
     dd_batch_offsets(b, pair_off.data(), nullptr, nullptr);
     dd_pair_sum_offsets(b, hh_off.data());
     if (hh_off[W] == 0) return DD_SUCCESS;
-    DevBuf dev;
+    DeviceCtx &ctx = g_ctx.c;
+    if ((rc = ctx.reserve(device, (size_t)(2 * (W + 1) * 4 + 2 * (W + 1) * 8 + (sz.n_pairs + hh_off[W]) * 8 + 16 * 256), 0))) return rc;
+    DevBuf dev(ctx);
     dd_device_batch db;
     memset(&db, 0, sizeof(db));
     db.n_windows = W;
@@ -561,42 +629,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     rc = dd_build_tables(p, b->qual_table, b->n_qual, b->mapq_table, b->n_mapq, tables.data());
     if (rc < 0) return rc;
 
-    DevBuf dev;
-    dd_device_batch db;
-    memset(&db, 0, sizeof(db));
-    db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
-    db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
-    db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
-#define UP(field, n) if ((rc = dev.upload(&db.field, b->field, (size_t)(n)))) return rc
-    UP(win_hap_off, W + 1); UP(win_read_off, W + 1); UP(win_hap_start, W);
-    UP(hap_seq_off, sz.n_haps + 1); UP(hap_seq, sz.hap_bases);
-    UP(read_seq_off, sz.n_reads + 1); UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases);
-    UP(read_mqidx, sz.n_reads); UP(read_start, sz.n_reads); UP(read_flags, sz.n_reads);
-#undef UP
-    if (b->hap_var_off) {
-        if ((rc = dev.upload(&db.hap_var_off, b->hap_var_off, (size_t)sz.n_haps + 1))) return rc;
-        if ((rc = dev.upload(&db.hap_var, b->hap_var, (size_t)2 * b->hap_var_off[sz.n_haps]))) return rc;
-    }
-    if ((rc = dev.upload(&db.hap_window, (const int32_t *)hap_window.data(), hap_window.size()))) return rc;
-    if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
-    if ((rc = dev.upload(&db.win_hpos_off, (const int64_t *)hpos_off.data(), hpos_off.size()))) return rc;
-    if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
-    if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
-
-    dd_result dr;
-    memset(&dr, 0, sizeof(dr));
-    const size_t np = (size_t)sz.n_pairs;
-#define OUT(field, n) if (r->field && (rc = dev.alloc(&dr.field, (size_t)(n)))) return rc
-    OUT(ll, np); OUT(llOn, np); OUT(llOff, np); OUT(mLogBQ, np); OUT(offHap, np); OUT(numIndels, np);
-    OUT(numMismatch, np); OUT(nBQT, np); OUT(nmmBQT, np); OUT(nMMLeft, np); OUT(nMMRight, np); OUT(firstBase, np);
-    OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT(status, np); OUT(onHap, sz.n_reads);
-#undef OUT
-    if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
-
-    // Chunked, double-buffered execution: contiguous window blocks alternate between two streams, and the D2H
-    // of block c is issued after the kernel of block c+1 has been enqueued, so the copy engine drains results
-    // while the CUs work on the next block (with pageable user memory the copy call blocks the host thread, not
-    // the GPU).  Each stream has its own back-pointer scratch.
+    // ---- host-side planning first (no device work yet): length classes and scratch size ----
     // Ragged batches: haplotypes are grouped by the lane tiling they need (K) and reads by length class, and each
     // non-empty (K class, length class) gets its own launches — a single 170-bp haplotype or 250-bp read no longer
     // drags every pair of the batch onto the K=3 / long-read build.
@@ -633,12 +666,16 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
             rcls.assign(1, all);
         }
     }
+    dd_device_batch db;
+    memset(&db, 0, sizeof(db));
+    db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
+    db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
+    db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
     size_t ws_bytes = dd_workspace_bytes(p, &db);
     int n_classes = 0;
     for (auto &hc : hcls) {
         if (hc.haps.empty()) continue;
         n_classes++;
-        if ((rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;
         for (auto &rcl : rcls) {
             dd_device_batch tmp = db;
             tmp.max_hap_len = hc.max_hap; tmp.max_read_len = rcl.max_len;
@@ -647,17 +684,61 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
         }
     }
     const bool single_class = (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
+
+    // ---- device arena (cached per host thread) ----
+    const size_t np = (size_t)sz.n_pairs;
+    const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
+    const size_t in_bytes = (size_t)(W + 1) * (4 + 4 + 8 + 8 + 8) + (size_t)W * 4 + (size_t)(sz.n_haps + 1) * 8 + (size_t)sz.hap_bases +
+                            (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 8 +
+                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 40 * 256;
+    const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
+    const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
+    DeviceCtx &ctx = g_ctx.c;
+    if ((rc = ctx.reserve(device, in_bytes + out_bytes + 2 * (ws_bytes + 256), staged ? in_bytes + out_bytes : 0))) return rc;
+    DevBuf dev(ctx);
+    dev.staged = staged;
+#define UP(field, n) if ((rc = dev.upload(&db.field, b->field, (size_t)(n)))) return rc
+    UP(win_hap_off, W + 1); UP(win_read_off, W + 1); UP(win_hap_start, W);
+    UP(hap_seq_off, sz.n_haps + 1); UP(hap_seq, sz.hap_bases);
+    UP(read_seq_off, sz.n_reads + 1); UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases);
+    UP(read_mqidx, sz.n_reads); UP(read_start, sz.n_reads); UP(read_flags, sz.n_reads);
+#undef UP
+    if (b->hap_var_off) {
+        if ((rc = dev.upload(&db.hap_var_off, b->hap_var_off, (size_t)sz.n_haps + 1))) return rc;
+        if ((rc = dev.upload(&db.hap_var, b->hap_var, 2 * n_var))) return rc;
+    }
+    if ((rc = dev.upload(&db.hap_window, (const int32_t *)hap_window.data(), hap_window.size()))) return rc;
+    if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
+    if ((rc = dev.upload(&db.win_hpos_off, (const int64_t *)hpos_off.data(), hpos_off.size()))) return rc;
+    if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
+    if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
+    if (!single_class)
+        for (auto &hc : hcls)
+            if (!hc.haps.empty() && (rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;
+    if ((rc = dev.flush_uploads(ctx.s[0]))) return rc;       // staged mode: the one H2D copy
+    if (!staged) HIP_TRY(hipStreamSynchronize(nullptr));     // pageable uploads went through the null stream's DMA
+
+    dd_result dr;
+    memset(&dr, 0, sizeof(dr));
+    const size_t out_begin = DevBuf::align(dev.used);
+#define OUT(field, n) if (r->field && (rc = dev.alloc(&dr.field, (size_t)(n)))) return rc
+    OUT(ll, np); OUT(llOn, np); OUT(llOff, np); OUT(mLogBQ, np); OUT(offHap, np); OUT(numIndels, np);
+    OUT(numMismatch, np); OUT(nBQT, np); OUT(nmmBQT, np); OUT(nMMLeft, np); OUT(nMMRight, np); OUT(firstBase, np);
+    OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT(status, np); OUT(onHap, sz.n_reads);
+#undef OUT
+    if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
+    const size_t out_end = dev.used;
     unsigned char *ws[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++)
         if (ws_bytes && (rc = dev.alloc(&ws[i], ws_bytes))) return rc;
-    struct Streams {
-        hipStream_t s[2] = {nullptr, nullptr};
-        ~Streams() { for (int i = 0; i < 2; i++) if (s[i]) (void)hipStreamDestroy(s[i]); }
-    } streams;
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&streams.s[i], hipStreamNonBlocking));
-    HIP_TRY(hipDeviceSynchronize());           // inputs were uploaded on the null stream
+    struct { hipStream_t s[2]; } streams = {{ctx.s[0], ctx.s[1]}};
 
-    int n_chunks = (int)((sz.n_pairs + 999999) / 1000000);
+    // Chunked, double-buffered execution: contiguous window blocks alternate between two streams, and the D2H
+    // of block c is issued after the kernel of block c+1 has been enqueued, so the copy engine drains results
+    // while the CUs work on the next block (with pageable user memory the copy call blocks the host thread, not
+    // the GPU).  Each stream has its own back-pointer scratch.  Small (staged) batches run as one block on stream 0
+    // and come back with one D2H through the pinned mirror.
+    int n_chunks = staged ? 1 : (int)((sz.n_pairs + 999999) / 1000000);
     if (n_chunks > 64) n_chunks = 64;
     if (n_chunks > W) n_chunks = W;
     if (n_chunks < 1) n_chunks = 1;
@@ -707,11 +788,22 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
                 }
             }
         }
-        if (c > 0 && (rc = download(c - 1))) return rc;
+        if (!staged && c > 0 && (rc = download(c - 1))) return rc;
     }
-    if ((rc = download(n_chunks - 1))) return rc;
-    HIP_TRY(hipStreamSynchronize(streams.s[0]));
-    HIP_TRY(hipStreamSynchronize(streams.s[1]));
+    if (staged) {
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + out_begin, ctx.arena + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, streams.s[0]));
+        HIP_TRY(hipStreamSynchronize(streams.s[0]));
+#define BACK(field, n) if (r->field && (n)) memcpy(r->field, ctx.pinned + (reinterpret_cast<unsigned char *>(dr.field) - ctx.arena), (size_t)(n) * sizeof(*r->field))
+        BACK(ll, np); BACK(llOn, np); BACK(llOff, np); BACK(mLogBQ, np); BACK(offHap, np); BACK(offHapHMQ, np);
+        BACK(numIndels, np); BACK(numMismatch, np); BACK(nBQT, np); BACK(nmmBQT, np); BACK(nMMLeft, np); BACK(nMMRight, np);
+        BACK(firstBase, np); BACK(lastBase, np); BACK(status, np); BACK(hpos, sz.hpos_len); BACK(var_covered, sz.var_cov_len);
+        BACK(onHap, sz.n_reads);
+#undef BACK
+    } else {
+        if ((rc = download(n_chunks - 1))) return rc;
+        HIP_TRY(hipStreamSynchronize(streams.s[0]));
+        HIP_TRY(hipStreamSynchronize(streams.s[1]));
+    }
 #undef DOWN
     return DD_SUCCESS;
 }

@@ -150,6 +150,9 @@ int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos
 /* device >= 0: HIP device ordinal.  Synchronous.  Replaces the body of computeLikelihoods for a
  * batch of windows. */
 int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+/* The host-pointer entry points keep a device arena, a pinned staging mirror and two streams per host thread between
+ * calls (one window per call would otherwise be all allocation overhead); this frees them. */
+void dd_release_cache(void);
 
 /* ---- (2) device-pointer entry points ------------------------------------------------------ */
 /* Table block built on the host with libm (emission logs per quality, bMid priors per mapping
