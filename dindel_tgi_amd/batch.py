@@ -29,6 +29,7 @@ class Window:
     haps: List[str]
     reads: List[ReadRec]
     hap_vars: Optional[List[List[Tuple[int, int]]]] = None   # per hap: (startRead, endRead) of hap.indels then hap.snps
+    hap_var_flanks: Optional[List[List[Tuple[int, int, int]]]] = None   # per hap variant: (leftFlankRead, rightFlankRead, kind 0/1=DEL/2=INS)
 
 
 def phred_to_prob(phred):
@@ -48,7 +49,8 @@ class PackedBatch:
               "read_seq_off", "read_seq", "read_qidx", "read_mqidx", "read_start", "read_flags",
               "qual_table", "mapq_table"]
 
-    def __init__(self, **arrays):
+    def __init__(self, hap_var_flank=None, **arrays):
+        self.hap_var_flank = None if hap_var_flank is None else np.ascontiguousarray(hap_var_flank, dtype=np.int32)
         self.a = {}
         dt = dict(win_hap_off=np.int32, win_read_off=np.int32, win_hap_start=np.uint32, hap_seq_off=np.int32,
                   hap_seq=np.uint8, hap_var_off=np.int32, hap_var=np.int32, read_seq_off=np.int32,
@@ -105,6 +107,8 @@ class PackedBatch:
         b.qual_table = _ptr(a["qual_table"], capi.c_f64p)
         b.n_mapq = len(a["mapq_table"])
         b.mapq_table = _ptr(a["mapq_table"], capi.c_f64p)
+        if self.hap_var_flank is not None and len(self.hap_var_flank):
+            b.hap_var_flank = _ptr(self.hap_var_flank, capi.c_i32p)
         return b
 
     def slice_windows(self, w0, w1):
@@ -122,7 +126,8 @@ class PackedBatch:
             hap_var=a["hap_var"][2 * v0:2 * v1], read_seq_off=a["read_seq_off"][r0:r1 + 1] - rs0,
             read_seq=a["read_seq"][rs0:rs1], read_qidx=a["read_qidx"][rs0:rs1], read_mqidx=a["read_mqidx"][r0:r1],
             read_start=a["read_start"][r0:r1], read_flags=a["read_flags"][r0:r1],
-            qual_table=a["qual_table"], mapq_table=a["mapq_table"])
+            qual_table=a["qual_table"], mapq_table=a["mapq_table"],
+            hap_var_flank=None if self.hap_var_flank is None else self.hap_var_flank[3 * v0:3 * v1])
 
 
 def pack(windows: Sequence[Window]) -> PackedBatch:
@@ -130,6 +135,7 @@ def pack(windows: Sequence[Window]) -> PackedBatch:
     qmap, mqmap = {}, {}
     win_hap_off, win_read_off, win_hap_start = [0], [0], []
     hap_seq_off, hap_seq, hap_var_off, hap_var = [0], [], [0], []
+    hap_var_flank, any_flank = [], any(w.hap_var_flanks is not None for w in windows)
     read_seq_off, read_seq, read_qidx, read_mqidx, read_start, read_flags = [0], [], [], [], [], []
     for w in windows:
         win_hap_start.append(w.hap_start & 0xFFFFFFFF)
@@ -139,6 +145,10 @@ def pack(windows: Sequence[Window]) -> PackedBatch:
             vs = w.hap_vars[hi] if w.hap_vars is not None else []
             for s, e in vs:
                 hap_var += [int(s), int(e)]
+            fl = w.hap_var_flanks[hi] if w.hap_var_flanks is not None else [(0, 0, 0)] * len(vs)
+            assert len(fl) == len(vs)
+            for t in fl:
+                hap_var_flank += [int(t[0]), int(t[1]), int(t[2])]
             hap_var_off.append(hap_var_off[-1] + len(vs))
         win_hap_off.append(win_hap_off[-1] + len(w.haps))
         for r in w.reads:
@@ -172,19 +182,21 @@ def pack(windows: Sequence[Window]) -> PackedBatch:
         read_seq_off=read_seq_off, read_seq=np.frombuffer(b"".join(read_seq), dtype=np.uint8),
         read_qidx=np.array(read_qidx, dtype=np.uint8), read_mqidx=np.array(read_mqidx, dtype=np.uint8),
         read_start=np.array(read_start, dtype=np.uint32), read_flags=np.array(read_flags, dtype=np.uint8),
-        qual_table=qt, mapq_table=mt)
+        qual_table=qt, mapq_table=mt,
+        hap_var_flank=np.array(hap_var_flank, dtype=np.int32) if any_flank else None)
 
 
 RESULT_DTYPES = dict(ll=np.float64, llOn=np.float64, llOff=np.float64, mLogBQ=np.float64, offHap=np.uint8,
                      offHapHMQ=np.uint8, numIndels=np.int16, numMismatch=np.int16, nBQT=np.int16, nmmBQT=np.int16,
                      nMMLeft=np.int16, nMMRight=np.int16, firstBase=np.int16, lastBase=np.int16, hpos=np.int16,
-                     var_covered=np.uint8, status=np.int32, onHap=np.uint8)
+                     var_covered=np.uint8, status=np.int32, onHap=np.uint8, var_fcov=np.uint8)
 
 
 def result_lengths(pb: PackedBatch):
     n = {k: pb.n_pairs for k in RESULT_DTYPES}
     n["hpos"] = pb.hpos_len
     n["var_covered"] = pb.var_cov_len
+    n["var_fcov"] = pb.var_cov_len
     n["onHap"] = pb.n_reads
     return n
 

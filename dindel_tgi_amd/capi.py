@@ -28,7 +28,7 @@ class dd_params(C.Structure):
     _fields_ = [("pError", C.c_double), ("pMut", C.c_double), ("pFirstgLO", C.c_double),
                 ("mapQualThreshold", C.c_double), ("checkBaseQualThreshold", C.c_double),
                 ("maxLengthDel", C.c_int32), ("padCover", C.c_int32), ("bMid", C.c_int32),
-                ("forceReadOnHaplotype", C.c_int32), ("mapUnmappedReads", C.c_int32)]
+                ("forceReadOnHaplotype", C.c_int32), ("mapUnmappedReads", C.c_int32), ("maxMismatch", C.c_int32)]
 
     @classmethod
     def from_dict(cls, d):
@@ -43,12 +43,12 @@ class dd_params(C.Structure):
 
 def params_cli_defaults():
     """DInDel.cpp:3937-3949 + 4122-4157 (the set production runs use)."""
-    return dd_params(5e-4, 1e-5, 0.01, 100.0, 0.95, 5, 2, -1, 0, 0)
+    return dd_params(5e-4, 1e-5, 0.01, 100.0, 0.95, 5, 2, -1, 0, 0, 2)
 
 
 def params_struct_defaults():
     """ObservationModel.hpp:39-64."""
-    return dd_params(1e-4, 1e-4, 0.01, 100.0, 0.95, 10, 5, -1, 0, 0)
+    return dd_params(1e-4, 1e-4, 0.01, 100.0, 0.95, 10, 5, -1, 0, 0, 1)
 
 
 class dd_batch(C.Structure):
@@ -58,14 +58,14 @@ class dd_batch(C.Structure):
                 ("read_seq_off", c_i32p), ("read_seq", C.c_char_p), ("read_qidx", c_u8p), ("read_mqidx", c_u8p),
                 ("read_start", c_u32p), ("read_flags", c_u8p),
                 ("n_qual", C.c_int32), ("qual_table", c_f64p),
-                ("n_mapq", C.c_int32), ("mapq_table", c_f64p)]
+                ("n_mapq", C.c_int32), ("mapq_table", c_f64p), ("hap_var_flank", c_i32p)]
 
 
 RESULT_FIELDS = [("ll", c_f64p), ("llOn", c_f64p), ("llOff", c_f64p), ("mLogBQ", c_f64p),
                  ("offHap", c_u8p), ("offHapHMQ", c_u8p),
                  ("numIndels", c_i16p), ("numMismatch", c_i16p), ("nBQT", c_i16p), ("nmmBQT", c_i16p),
                  ("nMMLeft", c_i16p), ("nMMRight", c_i16p), ("firstBase", c_i16p), ("lastBase", c_i16p),
-                 ("hpos", c_i16p), ("var_covered", c_u8p), ("status", c_i32p), ("onHap", c_u8p)]
+                 ("hpos", c_i16p), ("var_covered", c_u8p), ("status", c_i32p), ("onHap", c_u8p), ("var_fcov", c_u8p)]
 
 
 class dd_result(C.Structure):
@@ -88,7 +88,7 @@ class dd_device_batch(C.Structure):
                 ("read_start", C.c_void_p), ("read_flags", C.c_void_p),
                 ("hap_window", C.c_void_p), ("win_pair_off", C.c_void_p), ("win_hpos_off", C.c_void_p),
                 ("win_varcov_off", C.c_void_p), ("tables", C.c_void_p),
-                ("n_qual", C.c_int32), ("n_mapq", C.c_int32)]
+                ("n_qual", C.c_int32), ("n_mapq", C.c_int32), ("hap_var_flank", C.c_void_p)]
 
 
 class dd_device_result(C.Structure):

@@ -291,13 +291,13 @@ void dd_params_struct_defaults(dd_params *p)
 {   // ObservationModelParameters::setDefaultValues — reference ObservationModel.hpp:39-64
     p->pError = 1e-4; p->pMut = 1e-4; p->pFirstgLO = 0.01; p->mapQualThreshold = 100.0;
     p->checkBaseQualThreshold = 0.95; p->maxLengthDel = 10; p->padCover = 5; p->bMid = -1;
-    p->forceReadOnHaplotype = 0; p->mapUnmappedReads = 0;
+    p->forceReadOnHaplotype = 0; p->mapUnmappedReads = 0; p->maxMismatch = 1;
 }
 
 void dd_params_cli_defaults(dd_params *p)
 {   // what main() installs — reference DInDel.cpp:3937-3949 with the option defaults at :4122-4157
     dd_params_struct_defaults(p);
-    p->pError = 5e-4; p->pMut = 1e-5; p->maxLengthDel = 5; p->mapQualThreshold = 100.0; p->padCover = 2;
+    p->pError = 5e-4; p->pMut = 1e-5; p->maxLengthDel = 5; p->mapQualThreshold = 100.0; p->padCover = 2; p->maxMismatch = 2;
 }
 
 int dd_batch_sizes(const dd_batch *b, dd_sizes *out)
@@ -455,7 +455,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     memset(&A, 0, sizeof(A));
     A.n_windows = b->n_windows; A.n_haps = b->n_haps; A.n_reads = b->n_reads;
     A.win_hap_off = b->win_hap_off; A.win_read_off = b->win_read_off; A.win_hap_start = b->win_hap_start;
-    A.hap_seq_off = b->hap_seq_off; A.hap_seq = b->hap_seq; A.hap_var_off = b->hap_var_off; A.hap_var = b->hap_var;
+    A.hap_seq_off = b->hap_seq_off; A.hap_seq = b->hap_seq; A.hap_var_off = b->hap_var_off; A.hap_var = b->hap_var; A.hap_var_flank = b->hap_var_flank;
     A.read_seq_off = b->read_seq_off; A.read_seq = b->read_seq; A.read_qidx = b->read_qidx; A.read_mqidx = b->read_mqidx;
     A.read_start = b->read_start; A.read_flags = b->read_flags;
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
@@ -465,7 +465,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     A.dbg = g_dbg;
 #endif
     A.always_ro = getenv("DD_ALWAYS_RO") ? 1 : 0;
-    A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid;
+    A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid; A.maxMismatch = p->maxMismatch;
     Plan pl;
     const int cls_hap = lc ? lc->max_hap_len : b->max_hap_len, cls_read = lc ? lc->max_read_len : b->max_read_len;
     rc = make_plan(p, cls_hap, cls_read, b->n_qual, pl, A);
@@ -689,9 +689,9 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     const size_t np = (size_t)sz.n_pairs;
     const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
     const size_t in_bytes = (size_t)(W + 1) * (4 + 4 + 8 + 8 + 8) + (size_t)W * 4 + (size_t)(sz.n_haps + 1) * 8 + (size_t)sz.hap_bases +
-                            (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 8 +
+                            (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 20 +
                             (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 40 * 256;
-    const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
+    const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + 2 * (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
     const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
     DeviceCtx &ctx = g_ctx.c;
     if ((rc = ctx.reserve(device, in_bytes + out_bytes + 2 * (ws_bytes + 256), staged ? in_bytes + out_bytes : 0))) return rc;
@@ -706,6 +706,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     if (b->hap_var_off) {
         if ((rc = dev.upload(&db.hap_var_off, b->hap_var_off, (size_t)sz.n_haps + 1))) return rc;
         if ((rc = dev.upload(&db.hap_var, b->hap_var, 2 * n_var))) return rc;
+        if (b->hap_var_flank && (rc = dev.upload(&db.hap_var_flank, b->hap_var_flank, 3 * n_var))) return rc;
     }
     if ((rc = dev.upload(&db.hap_window, (const int32_t *)hap_window.data(), hap_window.size()))) return rc;
     if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
@@ -725,6 +726,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     OUT(ll, np); OUT(llOn, np); OUT(llOff, np); OUT(mLogBQ, np); OUT(offHap, np); OUT(numIndels, np);
     OUT(numMismatch, np); OUT(nBQT, np); OUT(nmmBQT, np); OUT(nMMLeft, np); OUT(nMMRight, np); OUT(firstBase, np);
     OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT(status, np); OUT(onHap, sz.n_reads);
+    OUT(var_fcov, sz.var_cov_len);
 #undef OUT
     if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
     const size_t out_end = dev.used;
@@ -760,6 +762,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
         DOWN(nMMRight, p0, pn); DOWN(firstBase, p0, pn); DOWN(lastBase, p0, pn); DOWN(status, p0, pn);
         DOWN(hpos, hpos_off[w0], hpos_off[w1] - hpos_off[w0]);
         DOWN(var_covered, vc_off[w0], vc_off[w1] - vc_off[w0]);
+        DOWN(var_fcov, vc_off[w0], vc_off[w1] - vc_off[w0]);
         DOWN(onHap, b->win_read_off[w0], b->win_read_off[w1] - b->win_read_off[w0]);
         return DD_SUCCESS;
     };
@@ -797,7 +800,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
         BACK(ll, np); BACK(llOn, np); BACK(llOff, np); BACK(mLogBQ, np); BACK(offHap, np); BACK(offHapHMQ, np);
         BACK(numIndels, np); BACK(numMismatch, np); BACK(nBQT, np); BACK(nmmBQT, np); BACK(nMMLeft, np); BACK(nMMRight, np);
         BACK(firstBase, np); BACK(lastBase, np); BACK(status, np); BACK(hpos, sz.hpos_len); BACK(var_covered, sz.var_cov_len);
-        BACK(onHap, sz.n_reads);
+        BACK(onHap, sz.n_reads); BACK(var_fcov, sz.var_cov_len);
 #undef BACK
     } else {
         if ((rc = download(n_chunks - 1))) return rc;

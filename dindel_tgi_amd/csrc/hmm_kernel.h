@@ -34,7 +34,7 @@ struct KernelArgs {
     const uint32_t *win_hap_start;
     const int32_t *hap_seq_off;
     const char *hap_seq;
-    const int32_t *hap_var_off, *hap_var;
+    const int32_t *hap_var_off, *hap_var, *hap_var_flank;
     const int32_t *read_seq_off;
     const char *read_seq;
     const uint8_t *read_qidx, *read_mqidx;
@@ -45,7 +45,7 @@ struct KernelArgs {
     const double *tables;
     dd_result out;
     /* params */
-    int32_t D, maxLengthDel, padCover, bMid;
+    int32_t D, maxLengthDel, padCover, bMid, maxMismatch;
     int32_t always_ro;                   /* 1: never skip the RO sink chain speculatively (diagnostics / A-B) */
     /* launch geometry */
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */

@@ -792,6 +792,39 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             }
         }
 
+        // filterHaplotypes' per-read coverage test of the haplotype's own indels (next row N1; reference
+        // DInDel.cpp:1951-2062): a selected read (!offHapHMQ && numIndels==0) has consecutive hpos values, so the set of
+        // haplotype bases it covers inside [left,right] is the overlap with [firstBase,lastBase].
+        if (P.out.var_fcov && P.hap_var_flank && nv > 0) {
+            const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
+            const bool sel = !offHapHMQ && nIndel == 0;
+            for (int i = 0; i < nv; i++) {
+                const int32_t *fl = P.hap_var_flank + 3 * (size_t)(P.hap_var_off[g] + i);
+                const int left = fl[0] - P.padCover, right = fl[1] + P.padCover, kind = fl[2];
+                int cov = 0;
+                if (sel && kind != 0) {
+                    int nmm = 0;
+                    for (int b0 = 0; b0 < L; b0 += 64) {
+                        const int b = b0 + lane;
+                        bool mm = false;
+                        if (b < L) {
+                            const int s = ms[b];
+                            if (s >= 1 && s <= Hs) {                          // on a haplotype base (no inserted states here)
+                                const int hb = s - 1;
+                                const int hc = sc[s];
+                                mm = hb >= left && hb <= right && (int)rdC[b] != hc && (kind == 2 || hc != 4);   // 'N' exempt for DEL (:1992)
+                            }
+                        }
+                        nmm += __popcll(__ballot(mm));
+                    }
+                    const int lo = firstB > left ? firstB : left, hi = lastB < right ? lastB : right;
+                    const int csize = (firstB >= 0 && hi >= lo) ? hi - lo + 1 : 0;
+                    cov = (csize >= right - left + 1 && nmm <= P.maxMismatch) ? 1 : 0;
+                }
+                if (lane == 0) P.out.var_fcov[vb + i] = (uint8_t)cov;
+            }
+        }
+
         if (lane == 0) {
             int status = DD_PAIR_OK;
             if (ll > 0.1) status = DD_PAIR_LLPOS;                         // DInDel.cpp:1722

@@ -51,6 +51,8 @@ class DeviceBatch:
         t["win_hpos_off"] = _to_dev(ho, self.device)
         t["win_varcov_off"] = _to_dev(vo, self.device)
         t["tables"] = _to_dev(tables, self.device)
+        if pb.hap_var_flank is not None and len(pb.hap_var_flank):
+            t["hap_var_flank"] = _to_dev(pb.hap_var_flank, self.device)
         self.t = t
         db = capi.dd_device_batch()
         db.n_windows, db.n_haps, db.n_reads = pb.n_windows, pb.n_haps, pb.n_reads

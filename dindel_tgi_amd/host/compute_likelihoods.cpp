@@ -24,6 +24,7 @@ static dd_params to_abi(const ObservationModelParameters &o)
     p.pError = o.pError; p.pMut = o.pMut; p.pFirstgLO = o.pFirstgLO; p.mapQualThreshold = o.mapQualThreshold;
     p.checkBaseQualThreshold = o.checkBaseQualThreshold; p.maxLengthDel = o.maxLengthDel; p.padCover = o.padCover;
     p.bMid = o.bMid; p.forceReadOnHaplotype = o.forceReadOnHaplotype ? 1 : 0; p.mapUnmappedReads = o.mapUnmappedReads ? 1 : 0;
+    p.maxMismatch = o.maxMismatch;
     return p;
 }
 
@@ -117,7 +118,7 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
 {
     const int W = int(jobs.size());
     // ---- pack (CSR) ----
-    std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, read_seq_off(1, 0);
+    std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, hap_var_flank, read_seq_off(1, 0);
     std::vector<uint32_t> win_hap_start, read_start;
     std::string hap_seq, read_seq;
     std::vector<uint8_t> read_qidx, read_mqidx, read_flags;
@@ -133,9 +134,12 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
             hap_seq_off.push_back(int32_t(hap_seq.size()));
             for (std::map<int, AlignedVariant>::const_iterator it = H.indels.begin(); it != H.indels.end(); ++it) {
                 hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
+                hap_var_flank.push_back(it->second.getLeftFlankRead()); hap_var_flank.push_back(it->second.getRightFlankRead());
+                hap_var_flank.push_back(it->second.getType() == AlignedVariant::DEL ? 1 : it->second.getType() == AlignedVariant::INS ? 2 : 0);
             }
             for (std::map<int, AlignedVariant>::const_iterator it = H.snps.begin(); it != H.snps.end(); ++it) {
                 hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
+                hap_var_flank.push_back(0); hap_var_flank.push_back(0); hap_var_flank.push_back(0);
             }
             hap_var_off.push_back(int32_t(hap_var.size() / 2));
         }
@@ -166,6 +170,7 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
     B.win_hap_off = win_hap_off.data(); B.win_read_off = win_read_off.data(); B.win_hap_start = win_hap_start.data();
     B.hap_seq_off = hap_seq_off.data(); B.hap_seq = hap_seq.data(); B.hap_var_off = hap_var_off.data();
     B.hap_var = hap_var.empty() ? NULL : hap_var.data();
+    B.hap_var_flank = hap_var_flank.empty() ? NULL : hap_var_flank.data();
     B.read_seq_off = read_seq_off.data(); B.read_seq = read_seq.data(); B.read_qidx = read_qidx.data();
     B.read_mqidx = read_mqidx.data(); B.read_start = read_start.data(); B.read_flags = read_flags.data();
     B.n_qual = int(qtab.size()); B.qual_table = qtab.data(); B.n_mapq = int(mqtab.size()); B.mapq_table = mqtab.data();
@@ -179,11 +184,13 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
     std::vector<uint8_t> offHap(sz.n_pairs), offHapHMQ(sz.n_pairs), onHapV(sz.n_reads ? sz.n_reads : 1);
     std::vector<int16_t> hpos(sz.hpos_len ? sz.hpos_len : 1);
     std::vector<int32_t> status(sz.n_pairs);
+    std::vector<uint8_t> fcov(sz.var_cov_len ? sz.var_cov_len : 1);
     dd_result Rz;
     memset(&Rz, 0, sizeof(Rz));
     Rz.ll = ll.data(); Rz.llOn = llOn.data(); Rz.llOff = llOff.data(); Rz.mLogBQ = mLogBQ.data();
     Rz.offHap = offHap.data(); Rz.offHapHMQ = offHapHMQ.data(); Rz.hpos = hpos.data(); Rz.status = status.data();
     Rz.onHap = onHapV.data();
+    Rz.var_fcov = fcov.data();
     const dd_params P = to_abi(params);
     if (sz.n_pairs > 0) {
         const int rc = dd_compute_likelihoods(&P, &B, &Rz, device_);
@@ -208,6 +215,15 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
                 ml.ll = ll[p]; ml.llOn = llOn[p]; ml.llOff = llOff[p];
                 ml.offHap = offHap[p] != 0; ml.offHapHMQ = offHapHMQ[p] != 0;
                 ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
+                {   // per haplotype-indel coverage flags of filterHaplotypes, in hap.indels map order (first nvI of the hap's list)
+                    const Haplotype &Hh = (*J.haps)[h];
+                    const int g = win_hap_off[w] + int(h);
+                    const int nv = hap_var_off[g + 1] - hap_var_off[g];
+                    const int64_t vb = vc_off[w] + int64_t(hap_var_off[g] - hap_var_off[win_hap_off[w]]) * int64_t(Rn) + int64_t(r) * nv;
+                    int i = 0;
+                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
+                        ml.hapIndelFilterCovered[it->first] = fcov[vb + i] != 0;
+                }
                 if (!ml.offHapHMQ) (*J.onHap)[r] = 1;                                     // DInDel.cpp:1720
                 if (status[p] == DD_PAIR_LLPOS) {                                         // DInDel.cpp:1722-1731
                     if (throwOnPositive_) { J.error = "Likelihood>0"; break; }

@@ -21,10 +21,12 @@ namespace dindel {
 class AlignedVariant {
 public:
     enum Type { INS, DEL, SNP, REF };
-    AlignedVariant() : type(REF), length(0), startHap(-1), endHap(-1), startRead(-1), endRead(-1) {}
+    AlignedVariant() : type(REF), length(0), startHap(-1), endHap(-1), startRead(-1), endRead(-1),
+                       leftFlankHap(-1), rightFlankHap(-1), leftFlankRead(-1), rightFlankRead(-1) {}
     // "+SEQ" insertion, "-SEQ" deletion, "X=>Y" SNP — reference Variant.hpp:43-74
     AlignedVariant(const std::string &s, int _startHap, int _endHap, int _startRead, int _endRead)
-        : str(s), startHap(_startHap), endHap(_endHap), startRead(_startRead), endRead(_endRead)
+        : str(s), startHap(_startHap), endHap(_endHap), startRead(_startRead), endRead(_endRead),
+          leftFlankHap(_startHap), rightFlankHap(_endHap), leftFlankRead(_startRead), rightFlankRead(_endRead)   // Variant.hpp:88-94
     {
         if (s.size() > 1 && s[0] == '-') { type = DEL; length = int(s.size()) - 1; seq = s.substr(1); }
         else if (s.size() > 1 && s[0] == '+') { type = INS; length = int(s.size()) - 1; seq = s.substr(1); }
@@ -41,6 +43,12 @@ public:
     int getEndHap() const { return endHap; }
     int getStartRead() const { return startRead; }
     int getEndRead() const { return endRead; }
+    // flanking coordinates — reference Variant.hpp:148-160 (set by the haplotype-to-reference alignment)
+    int getLeftFlankHap() const { return leftFlankHap; }
+    int getRightFlankHap() const { return rightFlankHap; }
+    int getLeftFlankRead() const { return leftFlankRead; }
+    int getRightFlankRead() const { return rightFlankRead; }
+    void setFlanking(int lfh, int rfh, int lfr, int rfr) { leftFlankHap = lfh; rightFlankHap = rfh; leftFlankRead = lfr; rightFlankRead = rfr; }
     // reference Variant.hpp:125-128
     bool isCovered(int pad, int firstBase, int lastBase) const
     {
@@ -52,6 +60,7 @@ private:
     int length;
     int startHap, endHap;     // position of the variant in the haplotype the read is aligned to
     int startRead, endRead;   // position of the variant in the read aligned to the haplotype
+    int leftFlankHap, rightFlankHap, leftFlankRead, rightFlankRead;
 };
 
 class MLAlignment {
@@ -64,6 +73,9 @@ public:
     int firstBase, lastBase;
     std::map<int, AlignedVariant> indels, snps;
     std::map<int, bool> hapIndelCovered, hapSNPCovered;
+    // not in the reference record: filterHaplotypes' per-read coverage test of each haplotype indel (DInDel.cpp:1973-2054),
+    // evaluated on the device next to hpos so the host reduction does not have to re-scan hpos
+    std::map<int, bool> hapIndelFilterCovered;
     double ll, llOn, llOff;
     bool offHap, offHapHMQ;
     int hl, hr;
@@ -88,15 +100,18 @@ public:
 
 class Read {
 public:
-    Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false) {}
+    Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false), reverse(false), mateReverse(false) {}
     Haplotype seq;                       // read.seq.seq is the base string, as in the reference
     std::vector<double> qual;            // P(base correct) — reference Read.hpp:143-148
     double mapQual;                      // P(mapping correct) — reference Read.hpp:127-131
     std::pair<double, double> posStat;   // .first: mean first-base position — reference Read.hpp:261-306
     uint32_t pos;
     bool unmapped;                       // BAM flag 0x4 (the reference reads bam->core.flag, Read.hpp:200)
+    bool reverse, mateReverse;           // BAM flags 0x10 / 0x20 (Read.hpp:201-203)
     size_t size() const { return seq.size(); }
     bool isUnmapped() const { return unmapped; }
+    bool isReverse() const { return reverse; }
+    bool mateIsReverse() const { return mateReverse; }
     void setAllQual(double v) { qual.assign(seq.size(), v); }
     // Phred -> probability exactly as the BAM constructor does — reference Read.hpp:127-131, 143-148
     static double phredToProb(double phred);

@@ -1,6 +1,7 @@
 // genotype.cpp — see genotype.hpp.
 #include "genotype.hpp"
 #include <cmath>
+#include <set>
 #include <string>
 
 namespace dindel {
@@ -39,6 +40,51 @@ PairPosteriorResult diploidPairPosteriors(int nh, const std::vector<double> &pai
     R.qual = -10.0 * (R.ll_ref - addLogs(R.max_ll_indel, R.ll_ref)) / log(10.0);         // :3118
     if (R.max_indel_pair[0] == -1 || R.max_indel_pair[1] == -1) throw std::string("Could not find indel allele");   // :3121
     return R;
+}
+
+void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
+                      const std::vector<std::vector<MLAlignment> > &liks, std::vector<int> &filtered,
+                      std::map<VariantKey, VariantCoverage> &varCoverage, bool doFilter)
+{
+    const int numHaps = int(haps.size());
+    filtered = std::vector<int>(haps.size(), 0);
+    varCoverage.clear();
+    std::map<VariantKey, std::vector<std::set<int> > > hVarCoverage;
+    for (int h = 0; h < numHaps; h++) {
+        std::set<int> selReads;                                              // :1951-1955
+        for (size_t r = 0; r < reads.size(); r++)
+            if (!liks[h][r].offHapHMQ && liks[h][r].numIndels == 0) selReads.insert(int(r));
+        bool allCovered = true;
+        for (std::map<int, AlignedVariant>::const_iterator it = haps[h].indels.begin(); it != haps[h].indels.end(); ++it) {
+            const AlignedVariant &av = it->second;
+            const VariantKey pav(it->first, av.getString());
+            if (hVarCoverage.find(pav) == hVarCoverage.end()) hVarCoverage[pav] = std::vector<std::set<int> >(haps.size() * 2);
+            if (av.getType() == AlignedVariant::INS || av.getType() == AlignedVariant::DEL) {
+                bool covered = false;
+                for (std::set<int>::const_iterator rt = selReads.begin(); rt != selReads.end(); ++rt) {
+                    const int r = *rt;
+                    int strand = 0;                                          // :1982-1987
+                    if (reads[r].isUnmapped()) { if (!reads[r].mateIsReverse()) strand = 1; }
+                    else { if (reads[r].isReverse()) strand = 1; }
+                    std::map<int, bool>::const_iterator f = liks[h][r].hapIndelFilterCovered.find(it->first);
+                    if (f != liks[h][r].hapIndelFilterCovered.end() && f->second) {
+                        hVarCoverage[pav][h + strand * numHaps].insert(r);
+                        covered = true;
+                    }
+                }
+                if (!covered) { allCovered = false; break; }                 // :2060-2063
+            }
+        }
+        if (doFilter && !allCovered) filtered[h] = 1;                        // :2068-2073
+    }
+    for (std::map<VariantKey, std::vector<std::set<int> > >::const_iterator it = hVarCoverage.begin(); it != hVarCoverage.end(); ++it) {
+        std::set<int> rf, rr;                                                // :2088-2097
+        for (int h = 0; h < numHaps; h++) if (filtered[h] != 1) {
+            rf.insert(it->second[h].begin(), it->second[h].end());
+            rr.insert(it->second[h + numHaps].begin(), it->second[h + numHaps].end());
+        }
+        varCoverage[it->first] = VariantCoverage(int(rf.size()), int(rr.size()));
+    }
 }
 
 } // namespace dindel

@@ -31,6 +31,10 @@ static void json_ml(std::ostringstream &os, const MLAlignment &ml)
     first = true;
     for (std::map<int, bool>::const_iterator it = ml.hapIndelCovered.begin(); it != ml.hapIndelCovered.end(); ++it, first = false)
         os << (first ? "" : ",") << "[" << it->first << "," << int(it->second) << "]";
+    os << "],\"hapIndelFilterCovered\":[";
+    first = true;
+    for (std::map<int, bool>::const_iterator it = ml.hapIndelFilterCovered.begin(); it != ml.hapIndelFilterCovered.end(); ++it, first = false)
+        os << (first ? "" : ",") << "[" << it->first << "," << int(it->second) << "]";
     os << "]}";
 }
 
@@ -135,6 +139,75 @@ int ddh_pair_posteriors(int nh, const double *pair_sum, const double *prior, con
         return 0;
     } catch (std::string &e) {
         return -1;
+    }
+}
+
+// GPU: one window with annotated haplotype indels through computeLikelihoods + filterHaplotypes.
+// hap_vars: per haplotype n then n x {key, kind(1 DEL,2 INS), leftFlankRead, rightFlankRead}; reads flags: bit0 unmapped, bit1 reverse, bit2 mate reverse
+int ddh_filter_window_json(const char *haps_nl, const int *hap_vars, const char *reads_nl, const double *quals, const double *mapq,
+                           const double *pos_first, const int *rflags, unsigned leftPos, const double *pd, const int *pi, int maxMismatch,
+                           int doFilter, int device, char *out, int cap)
+{
+    try {
+        std::vector<Haplotype> haps;
+        std::vector<Read> reads;
+        std::istringstream hs(haps_nl), rs(reads_nl);
+        std::string line;
+        const int *hv = hap_vars;
+        while (std::getline(hs, line)) {
+            if (line.empty()) continue;
+            Haplotype H(line);
+            const int n = *hv++;
+            for (int i = 0; i < n; i++, hv += 4) {
+                AlignedVariant av(hv[1] == 1 ? "-A" : "+A", hv[0], hv[0], hv[2], hv[3]);
+                av.setFlanking(hv[0], hv[0], hv[2], hv[3]);
+                H.indels[hv[0]] = av;
+            }
+            haps.push_back(H);
+        }
+        size_t qoff = 0, ri = 0;
+        while (std::getline(rs, line)) {
+            if (line.empty()) continue;
+            Read R;
+            R.seq.seq = line;
+            R.qual.assign(quals + qoff, quals + qoff + line.size());
+            qoff += line.size();
+            R.mapQual = mapq[ri]; R.posStat.first = pos_first[ri];
+            R.unmapped = (rflags[ri] & 1) != 0; R.reverse = (rflags[ri] & 2) != 0; R.mateReverse = (rflags[ri] & 4) != 0;
+            reads.push_back(R);
+            ri++;
+        }
+        ObservationModelParameters P = make_params(pd, pi);
+        P.maxMismatch = maxMismatch;
+        LikelihoodEngine eng(P, device);
+        std::vector<std::vector<MLAlignment> > liks;
+        std::vector<int> onHap, filtered;
+        eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        std::map<VariantKey, VariantCoverage> cov;
+        filterHaplotypes(haps, reads, liks, filtered, cov, doFilter != 0);
+        std::ostringstream os;
+        os << "{\"filtered\":[";
+        for (size_t i = 0; i < filtered.size(); i++) os << (i ? "," : "") << filtered[i];
+        os << "],\"coverage\":[";
+        bool first = true;
+        for (std::map<VariantKey, VariantCoverage>::const_iterator it = cov.begin(); it != cov.end(); ++it, first = false)
+            os << (first ? "" : ",") << "[" << it->first.first << ",\"" << it->first.second << "\"," << it->second.nf << "," << it->second.nr << "]";
+        os << "],\"flags\":[";
+        for (size_t h = 0; h < liks.size(); h++) {
+            os << (h ? "," : "") << "[";
+            for (size_t r = 0; r < liks[h].size(); r++) {
+                os << (r ? "," : "") << "[";
+                bool f2 = true;
+                for (std::map<int, bool>::const_iterator it = liks[h][r].hapIndelFilterCovered.begin(); it != liks[h][r].hapIndelFilterCovered.end(); ++it, f2 = false)
+                    os << (f2 ? "" : ",") << int(it->second);
+                os << "]";
+            }
+            os << "]";
+        }
+        os << "]}";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
     }
 }
 

@@ -19,28 +19,33 @@ ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 def generate(n_windows, H=8, R=200, L=100, hap_len=120, seed=0x9E3779B9, max_indel=3, sub_rate=1e-3,
              phred=30, mapq_phred=40, hap_start=1000, vary_read_len=False, mixed_quals=False) -> PackedBatch:
     rng = np.random.Generator(np.random.PCG64(seed))
-    hap_chunks, hap_lens, hap_var_off, hap_var = [], [], [0], []
+    hap_chunks, hap_lens, hap_var_off, hap_var, hap_var_flank = [], [], [0], [], []
     read_seq = np.empty(0, np.uint8)
     read_chunks, read_lens, read_start = [], [], []
     for _ in range(n_windows):
         ref = ACGT[rng.integers(0, 4, hap_len)]
         haps = [ref]
         hvars = [[]]
+        hflank = [[]]
         for _h in range(1, H):
             ln = int(rng.integers(1, max_indel + 1))
             pos = int(rng.integers(hap_len // 2 - 10, hap_len // 2 + 10))
             if rng.random() < 0.5:   # deletion of ln bases at pos
                 haps.append(np.concatenate([ref[:pos], ref[pos + ln:]]))
                 hvars.append([(pos - 1, pos)])          # flanking bases in the haplotype
+                hflank.append([(pos - 1, pos, 1)])      # (leftFlankRead, rightFlankRead, DEL)
             else:                    # insertion of ln random bases before pos
                 ins = ACGT[rng.integers(0, 4, ln)]
                 haps.append(np.concatenate([ref[:pos], ins, ref[pos:]]))
                 hvars.append([(pos, pos + ln - 1)])
-        for h, v in zip(haps, hvars):
+                hflank.append([(pos - 1, pos + ln, 2)])  # INS
+        for h, v, f in zip(haps, hvars, hflank):
             hap_chunks.append(h)
             hap_lens.append(len(h))
             for s, e in v:
                 hap_var += [s, e]
+            for t in f:
+                hap_var_flank += list(t)
             hap_var_off.append(hap_var_off[-1] + len(v))
         # reads (vectorised over the window's R reads)
         src = rng.integers(0, H, R)
@@ -87,7 +92,7 @@ def generate(n_windows, H=8, R=200, L=100, hap_len=120, seed=0x9E3779B9, max_ind
         hap_var_off=hap_var_off, hap_var=np.array(hap_var, np.int32),
         read_seq_off=np.concatenate([z, np.cumsum(np.concatenate(read_lens))]) if read_lens else z, read_seq=read_seq, read_qidx=read_qidx,
         read_mqidx=read_mqidx, read_start=np.concatenate(read_start) if read_start else np.empty(0, np.uint32), read_flags=np.zeros(n_reads, np.uint8),
-        qual_table=qual_table, mapq_table=mapq_table)
+        qual_table=qual_table, mapq_table=mapq_table, hap_var_flank=np.array(hap_var_flank, np.int32))
 
 
 def tile(pb: PackedBatch, reps: int) -> PackedBatch:
@@ -106,4 +111,5 @@ def tile(pb: PackedBatch, reps: int) -> PackedBatch:
         read_seq_off=rep_off(a["read_seq_off"]), read_seq=np.tile(a["read_seq"], reps),
         read_qidx=np.tile(a["read_qidx"], reps), read_mqidx=np.tile(a["read_mqidx"], reps),
         read_start=np.tile(a["read_start"], reps), read_flags=np.tile(a["read_flags"], reps),
-        qual_table=a["qual_table"], mapq_table=a["mapq_table"])
+        qual_table=a["qual_table"], mapq_table=a["mapq_table"],
+        hap_var_flank=None if pb.hap_var_flank is None else np.tile(pb.hap_var_flank, reps))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -76,6 +76,7 @@ typedef struct dd_params {
     int32_t bMid;                    /* -1 = compute from overlap (ObservationModelFB.cpp:96)        */
     int32_t forceReadOnHaplotype;    /* ObservationModelFB.cpp:307-316                               */
     int32_t mapUnmappedReads;        /* must be 0 (needs Library insert-size pmf; out of scope)      */
+    int32_t maxMismatch;             /* "flankMaxMismatch": used only by the filterHaplotypes coverage flags */
 } dd_params;
 
 /* ObservationModelParameters::setDefaultValues() — ObservationModel.hpp:39-64 */
@@ -116,6 +117,10 @@ typedef struct dd_batch {
 
     int32_t        n_qual;  const double *qual_table;  /* P(base correct), Read.hpp:143-148          */
     int32_t        n_mapq;  const double *mapq_table;  /* read.mapQual,    Read.hpp:127-131          */
+
+    const int32_t *hap_var_flank;  /* optional (NULL = none), per variant of hap_var, 3 ints:
+                                      {getLeftFlankRead(), getRightFlankRead(), kind}, kind 1 = DEL, 2 = INS,
+                                      0 = neither (SNP entries): inputs of filterHaplotypes, DInDel.cpp:1973-1976 */
 } dd_batch;
 
 /* Per (window,hap,read) pair, in pair order.  Any output pointer may be NULL (then not written),
@@ -129,6 +134,12 @@ typedef struct dd_result {
     uint8_t *var_covered; /* per (pair, variant of that hap): hapIndelCovered / hapSNPCovered        */
     int32_t *status;      /* DD_PAIR_*                                                               */
     uint8_t *onHap;       /* [n_reads] 1 iff any hap of the window has !offHapHMQ (DInDel.cpp:1720)  */
+    uint8_t *var_fcov;    /* next row N1, same indexing as var_covered: 1 iff the read counts as covering the
+                             haplotype's indel in DetInDel::filterHaplotypes (DInDel.cpp:1951-2062): read selected
+                             (!offHapHMQ && numIndels==0), every haplotype base of [leftFlank-padCover,
+                             rightFlank+padCover] aligned to, at most maxMismatch mismatches there.  Needs
+                             dd_batch.hap_var_flank.  (The reference loop also reads hpos[L], one past the end —
+                             undefined behaviour that is not reproduced.) */
 } dd_result;
 
 /* sizes derived from a batch (host-side, O(n_windows + n_haps)) */
@@ -177,6 +188,7 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
     const int32_t *hap_window; const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
     const double  *tables;          /* DD_TABLE_DOUBLES doubles from dd_build_tables               */
     int32_t n_qual, n_mapq;
+    const int32_t *hap_var_flank;   /* optional, see dd_batch */
 } dd_device_batch;
 
 /* bytes of device scratch dd_launch_device needs for this shape (0 if none) */

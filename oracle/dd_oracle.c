@@ -483,6 +483,39 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                         R->var_covered[vb + i] = (o.status != DD_PAIR_HAPSIZE && o.firstBase + P->padCover <= sR && o.lastBase - P->padCover >= eR) ? 1 : 0;
                     }
                 }
+                if (R->var_fcov && B->hap_var_flank && nv > 0) {
+                    /* DetInDel::filterHaplotypes inner test — DInDel.cpp:1951-1955 (selection), :1973-2006 (DEL),
+                     * :2011-2054 (INS); written with the reference's own set/loop structure (b < L: the reference's
+                     * b <= L reads one past hpos) */
+                    int64_t vb = vcbase + (int64_t)(B->hap_var_off[h] - B->hap_var_off[h0]) * Rn + (int64_t)(r - r0) * nv;
+                    int sel = (o.status != DD_PAIR_HAPSIZE && !o.offHapHMQ && o.numIndels == 0);
+                    for (i = 0; i < nv; i++) {
+                        const int32_t *fl = B->hap_var_flank + 3 * (size_t)(B->hap_var_off[h] + i);
+                        int left = fl[0] - P->padCover, right = fl[1] + P->padCover, kind = fl[2];
+                        int len = right - left + 1, cov = 0;
+                        if (sel && kind != 0 && len > 0) {
+                            char *cset = (char *)calloc((size_t)len, 1);
+                            int csize = 0, nmm = 0, bb, x;
+                            for (bb = 0; bb < L; bb++) {
+                                int hb = hp[bb];
+                                if (hb >= left && hb <= right) {
+                                    if (!cset[hb - left]) { cset[hb - left] = 1; csize++; }
+                                    if (kind == 1) { if (hs[hb] != 'N' && hs[hb] != B->read_seq[so + bb]) nmm++; }
+                                    else { if (hs[hb] != B->read_seq[so + bb]) nmm++; }
+                                }
+                            }
+                            if (kind == 1) cov = (csize >= len && nmm <= P->maxMismatch);
+                            else {
+                                int lenins = 0;          /* length of the inserted sequence is irrelevant to the outcome: */
+                                (void)lenins;            /* both branches of :2047 end up requiring every base covered   */
+                                cov = (nmm <= P->maxMismatch);
+                                for (x = 0; x < len; x++) if (!cset[x]) cov = 0;
+                            }
+                            free(cset);
+                        }
+                        R->var_fcov[vb + i] = (uint8_t)cov;
+                    }
+                }
                 if (R->onHap && o.status != DD_PAIR_HAPSIZE && !o.offHapHMQ) R->onHap[r] = 1;
             }
         }

@@ -59,3 +59,25 @@ def compute_window(haps, reads, quals, mapq, pos_first, unmapped, left_pos, para
                                     um.ctypes.data_as(capi.c_i32p), C.c_uint(left_pos & 0xFFFFFFFF), pd, pi, device, out, len(out))
     assert n > 0, n
     return json.loads(out.value.decode())
+
+
+def filter_window(haps, hap_vars, reads, quals, mapq, pos_first, rflags, left_pos, params, do_filter=True, device=0):
+    """computeLikelihoods + filterHaplotypes through the C++ host adapter.  hap_vars: per hap list of
+    (key, kind, leftFlankRead, rightFlankRead)."""
+    lib = load()
+    q = np.ascontiguousarray(np.concatenate([np.broadcast_to(np.asarray(x, np.float64), (len(r),)) for x, r in zip(quals, reads)]))
+    mq = np.asarray(mapq, np.float64); pf = np.asarray(pos_first, np.float64); rf = np.asarray(rflags, np.int32)
+    hv = []
+    for vs in hap_vars:
+        hv.append(len(vs))
+        for t in vs:
+            hv += list(t)
+    hv = np.asarray(hv, np.int32)
+    pd, pi = _params(params)
+    out = C.create_string_buffer(1 << 24)
+    n = lib.ddh_filter_window_json("\n".join(haps).encode(), hv.ctypes.data_as(capi.c_i32p), "\n".join(reads).encode(),
+                                   q.ctypes.data_as(capi.c_f64p), mq.ctypes.data_as(capi.c_f64p), pf.ctypes.data_as(capi.c_f64p),
+                                   rf.ctypes.data_as(capi.c_i32p), C.c_uint(left_pos & 0xFFFFFFFF), pd, pi, params.maxMismatch,
+                                   1 if do_filter else 0, device, out, len(out))
+    assert n > 0, n
+    return json.loads(out.value.decode())

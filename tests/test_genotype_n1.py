@@ -110,3 +110,64 @@ def test_device_pair_sums(lib, cfg):
     _oracle.load().ddo_pair_sums(C.byref(b), got["ll"].ctypes.data_as(capi.c_f64p), want.ctypes.data_as(capi.c_f64p))
     np.testing.assert_allclose(dev, want, rtol=1e-12, atol=0)     # tolerance: device exp/log vs glibc
     assert (dev[want == 0] == 0).all()
+
+
+def py_filter_flags(pb, params, res):
+    """filterHaplotypes' per-(haplotype variant, read) coverage test restated in Python straight from the reference
+    loop (DInDel.cpp:1951-2054), set-based like the reference; b < L (the reference's b <= L is out of bounds)."""
+    a = pb.a
+    out = np.zeros(pb.var_cov_len, np.uint8)
+    for w in range(pb.n_windows):
+        h0, h1 = a["win_hap_off"][w], a["win_hap_off"][w + 1]
+        r0, r1 = a["win_read_off"][w], a["win_read_off"][w + 1]
+        R = r1 - r0
+        SL = int(a["read_seq_off"][r1] - a["read_seq_off"][r0])
+        for h in range(h0, h1):
+            hap = bytes(a["hap_seq"][a["hap_seq_off"][h]:a["hap_seq_off"][h + 1]])
+            v0, v1 = a["hap_var_off"][h], a["hap_var_off"][h + 1]
+            for r in range(r0, r1):
+                p = int(pb.win_pair_off[w]) + (h - h0) * R + (r - r0)
+                s0, s1 = int(a["read_seq_off"][r]), int(a["read_seq_off"][r + 1])
+                read = bytes(a["read_seq"][s0:s1])
+                hp0 = int(pb.win_hpos_off[w]) + (h - h0) * SL + (s0 - int(a["read_seq_off"][r0]))
+                hpos = res["hpos"][hp0:hp0 + (s1 - s0)]
+                sel = (not res["offHapHMQ"][p]) and res["numIndels"][p] == 0
+                for i in range(v1 - v0):
+                    lf, rf, kind = pb.hap_var_flank[3 * (v0 + i):3 * (v0 + i) + 3]
+                    left, right = lf - params.padCover, rf + params.padCover
+                    ln = right - left + 1
+                    cov = 0
+                    if sel and kind != 0:
+                        c, nmm = set(), 0
+                        for b in range(len(hpos)):
+                            hb = int(hpos[b])
+                            if left <= hb <= right:
+                                c.add(hb)
+                                if kind == 1:
+                                    nmm += hap[hb:hb + 1] != b"N" and hap[hb] != read[b]
+                                else:
+                                    nmm += hap[hb] != read[b]
+                        cov = int(len(c) >= ln and nmm <= params.maxMismatch)
+                    out[int(pb.win_varcov_off[w]) + (v0 - a["hap_var_off"][h0]) * R + (r - r0) * (v1 - v0) + i] = cov
+    return out
+
+
+def test_oracle_filter_flags_match_python_restatement():
+    pb = synth.generate(4, H=5, R=30, L=60, hap_len=90, seed=13, sub_rate=0.02, mixed_quals=True)
+    p = capi.params_cli_defaults()
+    res = _oracle.batch(p, pb, nthreads=4)
+    want = py_filter_flags(pb, p, res)
+    assert np.array_equal(res["var_fcov"][:pb.var_cov_len], want)
+    assert 0 < want.sum() < want.size                       # both outcomes occur
+
+
+@pytest.mark.gpu
+def test_device_filter_flags(lib):
+    from tests.test_gpu_parity import run_host_api
+    for seed, kw in ((1, dict()), (2, dict(sub_rate=0.05, mixed_quals=True)), (3, dict(vary_read_len=True))):
+        pb = synth.generate(6, H=6, R=40, L=80, hap_len=110, seed=seed, **kw)
+        for p in (capi.params_cli_defaults(), capi.params_struct_defaults()):
+            got = run_host_api(lib, p, pb)
+            want = _oracle.batch(p, pb, nthreads=8)
+            assert np.array_equal(got["var_fcov"][:pb.var_cov_len], want["var_fcov"][:pb.var_cov_len])
+            assert np.array_equal(got["var_fcov"][:pb.var_cov_len], py_filter_flags(pb, p, got))

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "survey_kat.json")))["cases"]
 INT_KEYS = ["offHap", "offHapHMQ", "numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft", "nMMRight", "firstBase",
-            "lastBase", "hpos", "var_covered", "status", "onHap"]
+            "lastBase", "hpos", "var_covered", "status", "onHap", "var_fcov"]
 F64_KEYS = ["ll", "llOn", "llOff", "mLogBQ"]
 
 
@@ -35,8 +35,9 @@ def assert_same(got, want, pb, rel=0.0):
     ok = want["status"][:pb.n_pairs] != capi.DD_PAIR_HAPSIZE
     assert np.array_equal(got["status"][:pb.n_pairs], want["status"][:pb.n_pairs])
     for k in INT_KEYS:
-        if k in ("hpos", "var_covered", "onHap", "status"):
-            n = {"hpos": pb.hpos_len, "var_covered": pb.var_cov_len, "onHap": pb.n_reads, "status": pb.n_pairs}[k]
+        if k in ("hpos", "var_covered", "var_fcov", "onHap", "status"):
+            n = {"hpos": pb.hpos_len, "var_covered": pb.var_cov_len, "var_fcov": pb.var_cov_len, "onHap": pb.n_reads,
+                 "status": pb.n_pairs}[k]
             if k == "hpos" and not ok.all():
                 continue
             assert np.array_equal(got[k][:n], want[k][:n]), k

@@ -61,3 +61,69 @@ def test_engine_throws_reference_strings():
     p = capi.params_cli_defaults()
     res = _host.compute_window(["ACG"], ["ACGT"], [0.999], [0.9999], [0.0], [0], 0, p)
     assert res == {"throw": "hapSize error."}
+
+
+def test_engine_filter_haplotypes_matches_reference_loop():
+    """computeLikelihoods + filterHaplotypes (DInDel.cpp:1932-2100) on the GPU flags vs a Python restatement of the
+    reference loop run on the oracle's hpos."""
+    rng = np.random.default_rng(3)
+    ref = "".join(rng.choice(list("ACGT"), 100))
+    hapD = ref[:48] + ref[51:]                      # 3-bp deletion: flanks 47 | 48 in the haplotype
+    hapI = ref[:55] + "GATTA" + ref[55:]            # 5-bp insertion at 55..59: flanks 54 | 60
+    haps = [ref, hapD, hapI, ref[:48] + ref[51:55] + "GATTA" + ref[55:]]
+    hap_vars = [[], [(48, 1, 47, 48)], [(55, 2, 54, 60)], [(48, 1, 47, 48), (52, 2, 51, 57)]]
+    reads, quals, mapq, pos, flags = [], [], [], [], []
+    for i in range(40):
+        src = haps[i % 4]
+        off = int(rng.integers(0, len(src) - 40))
+        s = list(src[off:off + 40])
+        if i % 7 == 0:
+            s[int(rng.integers(0, 40))] = "A"
+        reads.append("".join(s)); quals.append(0.999); mapq.append(0.9999); pos.append(1000.0 + off)
+        flags.append([0, 2, 1, 5][i % 4])           # fwd, reverse, unmapped(mate fwd), unmapped(mate reverse)
+    p = capi.params_cli_defaults()
+    res = _host.filter_window(haps, hap_vars, reads, quals, mapq, pos, flags, 1000, p)
+    # ---- Python restatement on oracle results ----
+    nh = len(haps)
+    filtered = [0] * nh
+    cover = {}
+    for h, hap in enumerate(haps):
+        sel = []
+        al = {}
+        for r, read in enumerate(reads):
+            o, hpos = _oracle.pair(hap, read, quals[r], mapq[r], int(pos[r]), 1000, p, unmapped=bool(flags[r] & 1))
+            al[r] = hpos
+            if not o.offHapHMQ and o.numIndels == 0:
+                sel.append(r)
+        all_cov = True
+        for (key, kind, lf, rfl) in hap_vars[h]:
+            pav = (key, "-A" if kind == 1 else "+A")
+            cover.setdefault(pav, [set() for _ in range(2 * nh)])
+            left, right = lf - p.padCover, rfl + p.padCover
+            ln = right - left + 1
+            covered = False
+            for r in sel:
+                strand = (0 if (flags[r] & 4) else 1) if (flags[r] & 1) else (1 if (flags[r] & 2) else 0)
+                c, nmm = set(), 0
+                for b, hb in enumerate(al[r]):
+                    if left <= hb <= right:
+                        c.add(hb)
+                        nmm += (hap[hb] != reads[r][b]) and (kind == 2 or hap[hb] != "N")
+                if len(c) >= ln and nmm <= p.maxMismatch:
+                    cover[pav][h + strand * nh].add(r)
+                    covered = True
+            if not covered:
+                all_cov = False
+                break
+        if not all_cov:
+            filtered[h] = 1
+    want_cov = []
+    for pav in sorted(cover):
+        rf, rr = set(), set()
+        for h in range(nh):
+            if not filtered[h]:
+                rf |= cover[pav][h]; rr |= cover[pav][h + nh]
+        want_cov.append([pav[0], pav[1], len(rf), len(rr)])
+    assert res["filtered"] == filtered
+    assert res["coverage"] == want_cov
+    assert sum(c[2] + c[3] for c in want_cov) > 0
