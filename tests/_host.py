@@ -10,7 +10,7 @@ from dindel_tgi_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_DIR = os.path.join(ROOT, "dindel_tgi_amd", "host")
-LIB = os.path.join(HOST_DIR, "libdindel_host.so")
+LIB = os.environ.get("DD_HOST_LIB") or os.path.join(HOST_DIR, "libdindel_host.so")
 _lib = None
 
 

@@ -10,7 +10,7 @@ from dindel_tgi_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libdd_oracle.so")
+LIB = os.environ.get("DD_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libdd_oracle.so")
 MAXV = 64
 
 
