@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             }
             shC[i] = c;
         }
-        for (int i = tid; i < D; i += nthr) shY[i] = (double)i * II;
+        for (int i = tid; i < D; i += nthr) shY[i] = (i + 1 > Dr) ? NEG_INF : (double)i * II;   // y = i+1; jumps past the real D are off
         __syncthreads();
     }
     // ---- per-lane register constants for this haplotype (states past RO are switched off with -inf) ----
