@@ -109,3 +109,27 @@ def test_random_windows_against_oracle(full):
                   "nMMLeft", "nMMRight", "firstBase", "lastBase"):
             assert np.array_equal(dev.out[k][p0:p1].cpu().numpy(), want[k][:sh.n_pairs]), (k, w)
         assert np.array_equal(dev.out["hpos"][h0:h1].cpu().numpy(), want["hpos"][:sh.hpos_len])
+
+
+def test_host_pointer_path_chunked_pipeline_equals_device_path(full, lib):
+    """dd_compute_likelihoods on 1,600 windows = 2.56e6 pairs: runs as 3 pipelined window blocks on two streams;
+    every output must equal the single-launch device-pointer results for the same windows."""
+    import ctypes as C
+    from dindel_tgi_amd.batch import alloc_result
+    pb, p, dev = full
+    w0, w1 = 4000, 5600
+    sh = pb.slice_windows(w0, w1)
+    arrs, res = alloc_result(sh, fill=None)
+    b = sh.ctypes_batch()
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == 0, capi.last_error()
+    p0, p1 = int(pb.win_pair_off[w0]), int(pb.win_pair_off[w1])
+    h0, h1 = int(pb.win_hpos_off[w0]), int(pb.win_hpos_off[w1])
+    v0, v1 = int(pb.win_varcov_off[w0]), int(pb.win_varcov_off[w1])
+    r0, r1 = int(pb.a["win_read_off"][w0]), int(pb.a["win_read_off"][w1])
+    for k in ("ll", "llOn", "llOff", "mLogBQ", "offHap", "offHapHMQ", "numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft",
+              "nMMRight", "firstBase", "lastBase", "status"):
+        assert np.array_equal(arrs[k][:sh.n_pairs], dev.out[k][p0:p1].cpu().numpy()), k
+    assert np.array_equal(arrs["hpos"][:sh.hpos_len], dev.out["hpos"][h0:h1].cpu().numpy())
+    assert np.array_equal(arrs["var_covered"][:sh.var_cov_len], dev.out["var_covered"][v0:v1].cpu().numpy())
+    assert np.array_equal(arrs["var_fcov"][:sh.var_cov_len], dev.out["var_fcov"][v0:v1].cpu().numpy())
+    assert np.array_equal(arrs["onHap"][:sh.n_reads], dev.out["onHap"][r0:r1].cpu().numpy())

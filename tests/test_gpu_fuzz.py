@@ -71,7 +71,7 @@ def test_fuzz(lib, seed, max_hap, max_read, mld, bmid):
 @pytest.mark.parametrize("force", ["0", "1"])
 @pytest.mark.parametrize("seed,min_hap,max_hap,mld", [(21, 12, 60, 3), (22, 12, 60, 11), (23, 70, 125, 7), (24, 70, 125, 10),
                                                        (25, 130, 190, 5), (26, 130, 190, 9), (27, 200, 250, 2), (28, 200, 250, 10),
-                                                       (29, 260, 380, 5), (30, 400, 500, 4)])
+                                                       (29, 260, 380, 5), (30, 400, 500, 4), (31, 560, 700, 8), (32, 3, 40, 1)])
 def test_fuzz_every_build(lib, monkeypatch, force, seed, min_hap, max_hap, mld):
     """Same fuzz, but pinning the back-pointer placement (DD_FORCE_GBT=0: LDS tile, 1: HBM scratch = register-lean
     build) so that every (K, D-build, variant) instantiation meets adversarial input, not only the one the plan picks."""
