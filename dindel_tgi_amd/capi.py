@@ -28,7 +28,7 @@ class dd_params(C.Structure):
     _fields_ = [("pError", C.c_double), ("pMut", C.c_double), ("pFirstgLO", C.c_double),
                 ("mapQualThreshold", C.c_double), ("checkBaseQualThreshold", C.c_double),
                 ("maxLengthDel", C.c_int32), ("padCover", C.c_int32), ("bMid", C.c_int32),
-                ("forceReadOnHaplotype", C.c_int32), ("mapUnmappedReads", C.c_int32), ("maxMismatch", C.c_int32)]
+                ("forceReadOnHaplotype", C.c_int32), ("mapUnmappedReads", C.c_int32), ("maxMismatch", C.c_int32), ("capMapQualFast", C.c_double)]
 
     @classmethod
     def from_dict(cls, d):
@@ -43,12 +43,12 @@ class dd_params(C.Structure):
 
 def params_cli_defaults():
     """DInDel.cpp:3937-3949 + 4122-4157 (the set production runs use)."""
-    return dd_params(5e-4, 1e-5, 0.01, 100.0, 0.95, 5, 2, -1, 0, 0, 2)
+    return dd_params(5e-4, 1e-5, 0.01, 100.0, 0.95, 5, 2, -1, 0, 0, 2, 45.0)
 
 
 def params_struct_defaults():
     """ObservationModel.hpp:39-64."""
-    return dd_params(1e-4, 1e-4, 0.01, 100.0, 0.95, 10, 5, -1, 0, 0, 1)
+    return dd_params(1e-4, 1e-4, 0.01, 100.0, 0.95, 10, 5, -1, 0, 0, 1, 40.0)
 
 
 class dd_batch(C.Structure):

@@ -291,13 +291,13 @@ void dd_params_struct_defaults(dd_params *p)
 {   // ObservationModelParameters::setDefaultValues — reference ObservationModel.hpp:39-64
     p->pError = 1e-4; p->pMut = 1e-4; p->pFirstgLO = 0.01; p->mapQualThreshold = 100.0;
     p->checkBaseQualThreshold = 0.95; p->maxLengthDel = 10; p->padCover = 5; p->bMid = -1;
-    p->forceReadOnHaplotype = 0; p->mapUnmappedReads = 0; p->maxMismatch = 1;
+    p->forceReadOnHaplotype = 0; p->mapUnmappedReads = 0; p->maxMismatch = 1; p->capMapQualFast = 40.0;
 }
 
 void dd_params_cli_defaults(dd_params *p)
 {   // what main() installs — reference DInDel.cpp:3937-3949 with the option defaults at :4122-4157
     dd_params_struct_defaults(p);
-    p->pError = 5e-4; p->pMut = 1e-5; p->maxLengthDel = 5; p->mapQualThreshold = 100.0; p->padCover = 2; p->maxMismatch = 2;
+    p->pError = 5e-4; p->pMut = 1e-5; p->maxLengthDel = 5; p->mapQualThreshold = 100.0; p->padCover = 2; p->maxMismatch = 2; p->capMapQualFast = 45.0;
 }
 
 int dd_batch_sizes(const dd_batch *b, dd_sizes *out)

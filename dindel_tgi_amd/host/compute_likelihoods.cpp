@@ -25,6 +25,7 @@ static dd_params to_abi(const ObservationModelParameters &o)
     p.checkBaseQualThreshold = o.checkBaseQualThreshold; p.maxLengthDel = o.maxLengthDel; p.padCover = o.padCover;
     p.bMid = o.bMid; p.forceReadOnHaplotype = o.forceReadOnHaplotype ? 1 : 0; p.mapUnmappedReads = o.mapUnmappedReads ? 1 : 0;
     p.maxMismatch = o.maxMismatch;
+    p.capMapQualFast = o.capMapQualFast;
     return p;
 }
 

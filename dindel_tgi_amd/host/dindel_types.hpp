@@ -125,15 +125,15 @@ public:
     {
         pError = 1e-4; pMut = 1e-4; maxLengthIndel = 10; maxLengthDel = maxLengthIndel; mapQualThreshold = 100.0;
         pFirstgLO = 0.01; checkBaseQualThreshold = 0.95; bMid = -1; forceReadOnHaplotype = false;
-        mapUnmappedReads = false; padCover = 5; maxMismatch = 1;
+        mapUnmappedReads = false; padCover = 5; maxMismatch = 1; capMapQualFast = 40.0;
     }
     // what main() installs from the CLI defaults — reference DInDel.cpp:3937-3949, 4122-4157
     void setCLIDefaultValues()
     {
         setDefaultValues();
-        pError = 5e-4; pMut = 1e-5; maxLengthIndel = 5; maxLengthDel = 5; padCover = 2; maxMismatch = 2;
+        pError = 5e-4; pMut = 1e-5; maxLengthIndel = 5; maxLengthDel = 5; padCover = 2; maxMismatch = 2; capMapQualFast = 45.0;
     }
-    double pError, pMut, mapQualThreshold, pFirstgLO, checkBaseQualThreshold;
+    double pError, pMut, mapQualThreshold, pFirstgLO, checkBaseQualThreshold, capMapQualFast;
     int maxLengthIndel, maxLengthDel, bMid, padCover, maxMismatch;
     bool forceReadOnHaplotype, mapUnmappedReads;
 };

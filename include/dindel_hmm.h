@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 2
+#define DD_ABI_VERSION 3
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -77,6 +77,7 @@ typedef struct dd_params {
     int32_t forceReadOnHaplotype;    /* ObservationModelFB.cpp:307-316                               */
     int32_t mapUnmappedReads;        /* must be 0 (needs Library insert-size pmf; out of scope)      */
     int32_t maxMismatch;             /* "flankMaxMismatch": used only by the filterHaplotypes coverage flags */
+    double  capMapQualFast;          /* phred cap on the mapping quality in the --faster model (Faster.cpp:117); 40 / CLI 45 */
 } dd_params;
 
 /* ObservationModelParameters::setDefaultValues() — ObservationModel.hpp:39-64 */

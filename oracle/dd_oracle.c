@@ -560,3 +560,241 @@ int ddo_pair_sums(const dd_batch *B, const double *ll, double *out)
     }
     return 0;
 }
+
+/* ================= secondary path: ObservationModelS, "--faster" =================
+ * Restatement of reference Faster.cpp:42-681 + HapHash (Haplotype.hpp:315-384) as driven by
+ * DetInDel::computeLikelihoodsFaster (DInDel.cpp:1790-1833).  Pinned by the three ObservationModelS values of
+ * SURVEY §8(c) (S1 struct / S1 CLI / S2).  Reproduced on purpose: `if (hp>=0 || hp<hlen)` is always true, so
+ * offHap / offHapHMQ are always false (:491, :529); the final k-mer of the haplotype is never hashed
+ * (Haplotype.hpp:380); non-ACGT bases hash as 'A' (:364-368). */
+static int fast_map_char(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0; }
+
+static int cmp_int(const void *a, const void *b) { int x = *(const int *)a, y = *(const int *)b; return (x > y) - (x < y); }
+
+int ddo_pair_fast(const char *hap, int hlen, const char *readseq, const double *qual, int rlen,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, const dd_params *P, ddo_out *out, int *hpos)
+{
+    const int kmer = 4;
+    int r, s, x, y;
+    memset(out, 0, sizeof(*out));
+    out->firstBase = -1;
+    out->lastBase = -1;
+    if (P->maxLengthDel > hlen) { out->status = DD_PAIR_HAPSIZE; return DD_PAIR_HAPSIZE; }   /* Faster.cpp:47 (maxLengthIndel) */
+    if (rlen < kmer) { out->status = DD_PAIR_NAN; return DD_PAIR_NAN; }                      /* HapHash::convert throws (:343) */
+
+    /* computeBMid — Faster.cpp:60-88 */
+    int bMid;
+    {
+        uint32_t hapEnd = hapStart + (uint32_t)hlen;
+        uint32_t mReadStart = readStartU32;
+        uint32_t readEnd = mReadStart + (uint32_t)rlen - 1;
+        if (mReadStart > hapEnd) bMid = 0;
+        else if (readEnd < hapStart) bMid = rlen - 1;
+        else {
+            uint32_t olStart = (hapStart > mReadStart) ? hapStart : mReadStart;
+            uint32_t olEnd = (hapEnd > readEnd) ? readEnd : hapEnd;
+            int mid = ((int)olEnd - (int)olStart) / 2 + (int)olStart;
+            bMid = mid - (int)mReadStart;
+        }
+        if (bMid < 0) bMid = 0;
+        if (bMid >= rlen) bMid = rlen - 1;
+    }
+    out->bMid = bMid;
+
+    /* setupReadLikelihoods — :91-127 */
+    double *logMatch = (double *)malloc(sizeof(double) * rlen), *logMismatch = (double *)malloc(sizeof(double) * rlen);
+    for (r = 0; r < rlen; r++) {
+        double rq = qual[r];
+        double pr = rq * (1.0 - P->pMut);
+        logMatch[r] = log(.25 + .75 * pr);
+        logMismatch[r] = log(.75 + 1e-10 - .75 * pr);
+    }
+    double mq = 1.0 - mapQual;
+    if (-10.0 * log10(mq) > P->capMapQualFast) mq = pow(10.0, -P->capMapQualFast / 10.0);
+    const double pOffFirst = mq, pOffFirstHMQ = 1e-10;
+
+    /* AlignHash — :131-189 with HapHash::makeHash (Haplotype.hpp:378-381) */
+    int nrel = hlen + rlen + 8;
+    int *freq = (int *)calloc((size_t)nrel, sizeof(int));   /* index rpfb + rlen */
+    {
+        int xl = rlen - kmer;
+        for (x = 0; x <= xl; x++) {
+            unsigned key = 0;
+            for (y = 0; y < kmer; y++) key |= (unsigned)fast_map_char(readseq[x + y]) << (2 * y);
+            int hx;
+            for (hx = 0; hx < hlen - kmer; hx++) {
+                unsigned hk = 0;
+                for (y = 0; y < kmer; y++) hk |= (unsigned)fast_map_char(hap[hx + y]) << (2 * y);
+                if (hk == key) freq[hx - x + rlen]++;
+            }
+        }
+    }
+    int relPos[17], S = 0;
+    {   /* highest frequency first, ties by ascending relative position (map<int,set<int>> reversed, :159-181) */
+        int tot = 0;
+        while (tot < 15) {
+            int bestf = 0, besti = -1;
+            for (x = 0; x < nrel; x++) if (freq[x] > bestf) { bestf = freq[x]; besti = x; }
+            if (besti < 0) break;
+            relPos[S++] = besti - rlen;
+            freq[besti] = 0;
+            tot++;
+        }
+    }
+    free(freq);
+
+    /* SStateHMM — :253-576 */
+    const double EPSS = 1e-7;
+    relPos[S++] = -rlen;
+    qsort(relPos, (size_t)S, sizeof(int), cmp_int);
+    const int T = 2 * S;
+    double *tr = (double *)malloc(sizeof(double) * S * S), *trI = (double *)malloc(sizeof(double) * S * S);
+    double *alpha = (double *)malloc(sizeof(double) * (size_t)rlen * T), *obs = (double *)malloc(sizeof(double) * (size_t)rlen * S);
+    int *bt = (int *)calloc((size_t)rlen * T, sizeof(int)), *state = (int *)malloc(sizeof(int) * rlen), *mapState = (int *)calloc((size_t)rlen, sizeof(int));
+    for (x = 0; x < S * S; x++) { tr[x] = -1000.0; trI[x] = -1000.0; }
+    for (x = 0; x < rlen * T; x++) alpha[x] = -1000.0;
+    for (r = 0; r < rlen; r++) state[r] = -1;
+    for (r = 0; r < rlen; r++)
+        for (s = 0; s < S; s++) {
+            int p1 = relPos[s];
+            if (p1 + r >= 0 && p1 + r < hlen) obs[r * S + s] = (readseq[r] == hap[p1 + r]) ? logMatch[r] : logMismatch[r];
+            else obs[r * S + s] = logMatch[r];
+        }
+    double prior[34], priorHMQ[34];
+    {
+        int ins;
+        for (ins = 0; ins < 2; ins++) {
+            double pins = (ins == 0) ? log(1.0 - P->pError) : log(P->pError);
+            for (y = 0; y < S; y++) {
+                int xx = y + ins * S;
+                int hp = relPos[y] + bMid;
+                if (hp >= 0 && hp < hlen) { prior[xx] = log(1.0 - pOffFirst) + pins; priorHMQ[xx] = log(1.0 - pOffFirstHMQ) + pins; }
+                else { prior[xx] = log(pOffFirst) + pins; priorHMQ[xx] = log(pOffFirstHMQ) + pins; }
+            }
+        }
+    }
+    const double logpInsgNoIns = log(P->pError);
+    const double logpInsgIns = -0.25;
+    const double logpNoInsgIns = log(1 - exp(logpInsgIns));
+    {
+        int s1, s2;
+        for (s1 = 0; s1 < S; s1++) for (s2 = 0; s2 < S; s2++) {
+            double ll = -1000.0;
+            if (s1 != s2) {
+                double d = fabs((double)(relPos[s1] - relPos[s2]));
+                ll = (d - 1.0) * logpInsgIns + log(P->pError);
+                trI[s1 * S + s2] = (d - 1.0) * logpInsgIns;
+            } else ll = log(1.0 - P->pError);
+            tr[s1 * S + s2] = ll;
+        }
+    }
+    for (r = 0; r < bMid; r++) {            /* from left to bMid (:373-416) */
+        int cr = r, cs, ns;
+        for (cs = 0; cs < S; cs++) {
+            double pv = obs[r * S + cs]; if (r) pv += alpha[(r - 1) * T + cs];
+            for (ns = cs; ns < S; ns++) {
+                double nv = pv + tr[cs * S + ns];
+                if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = cs; }
+            }
+            ns = cs + S;
+            double nv = pv + logpNoInsgIns;
+            if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = cs; }
+            int ics = cs + S;
+            ns = ics;
+            nv = logMatch[r] + logpInsgIns; if (r) nv += alpha[(r - 1) * T + ics];
+            if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = ics; }
+            for (ns = 0; ns < cs; ns++) if (relPos[cs] - r >= relPos[ns]) {
+                nv = logMatch[r] + trI[cs * S + ns] + logpInsgNoIns; if (r) nv += alpha[(r - 1) * T + ics];
+                if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = ics; }
+            }
+        }
+    }
+    for (r = rlen - 1; r > bMid; r--) {     /* from right to bMid (:422-466) */
+        int cr = r, cs, ns;
+        for (cs = 0; cs < S; cs++) {
+            double pv = obs[r * S + cs]; if (r < rlen - 1) pv += alpha[(r + 1) * T + cs];
+            for (ns = 0; ns <= cs; ns++) {
+                double nv = pv + tr[cs * S + ns];
+                if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = cs; }
+            }
+            double nv = logMatch[r] + logpInsgNoIns; if (r < rlen - 1) nv += alpha[(r + 1) * T + cs + S];
+            if (nv > alpha[cr * T + cs] + EPSS) { alpha[cr * T + cs] = nv; bt[cr * T + cs] = cs + S; }
+            int ics = cs + S;
+            ns = ics;
+            nv = logMatch[r] + logpInsgIns; if (r < rlen - 1) nv += alpha[(r + 1) * T + ics];
+            if (nv > alpha[cr * T + ns] + EPSS) { alpha[cr * T + ns] = nv; bt[cr * T + ns] = ics; }
+            for (ns = cs + 1; ns < S; ns++) if (relPos[cs] > relPos[ns] - r) {
+                nv = obs[r * S + cs] + logpNoInsgIns + trI[cs * S + ns]; if (r < rlen - 1) nv += alpha[(r + 1) * T + cs];
+                if (nv > alpha[cr * T + ns + S] + EPSS) { alpha[cr * T + ns + S] = nv; bt[cr * T + ns + S] = cs; }
+            }
+        }
+    }
+    double max = -HUGE_VAL;
+    int xmax = 0, ins;
+    for (ins = 0; ins < 2; ins++) for (y = 0; y < S; y++) {          /* :472-486 */
+        int xx = ins * S + y;
+        double obsv = (ins == 0) ? obs[bMid * S + y] : logMatch[bMid];
+        alpha[bMid * T + xx] = obsv + prior[xx];
+        if (bMid < rlen - 1) alpha[bMid * T + xx] += alpha[(bMid + 1) * T + xx];
+        if (bMid > 0) alpha[bMid * T + xx] += alpha[(bMid - 1) * T + xx];
+        if (alpha[bMid * T + xx] > max) { max = alpha[bMid * T + xx]; xmax = xx; }
+    }
+    out->offHap = 0;                     /* `if (hp>=0 || hp<hlen)` is always true (:491) */
+    out->ll = max;
+    max = -HUGE_VAL;
+    xmax = 0;
+    for (ins = 0; ins < 2; ins++) for (y = 0; y < S; y++) {          /* :510-526 */
+        int xx = ins * S + y;
+        double obsv = (ins == 0) ? obs[bMid * S + xx] : logMatch[bMid];
+        double v = obsv + priorHMQ[xx];
+        if (bMid < rlen - 1) v += alpha[(bMid + 1) * T + xx];
+        if (bMid > 0) v += alpha[(bMid - 1) * T + xx];
+        if (v > max) { max = v; xmax = xx; }
+    }
+    out->offHapHMQ = 0;                  /* same always-true test (:529) */
+    state[bMid] = xmax;
+    for (r = bMid; r > 0; r--) state[r - 1] = bt[(r - 1) * T + state[r]];
+    for (r = bMid; r < rlen - 1; r++) state[r + 1] = bt[(r + 1) * T + state[r]];
+    {
+        int lhp = 1;
+        for (r = 0; r < rlen; r++) {     /* :552-571 */
+            if (state[r] < S) {
+                int hp = relPos[state[r]] + r;
+                if (hp >= 0 && hp < hlen) { mapState[r] = hp + 1; lhp = hp + 1; }
+                else if (hp < 0) mapState[r] = 0; else mapState[r] = hlen;
+            } else mapState[r] = hlen + 2 + lhp;
+        }
+    }
+    /* reportVariants — :579-681 (numIndels etc. are not set by this model) */
+    {
+        const int numS = hlen + 2;
+        int b = 0;
+        while (b < rlen) {
+            int st = mapState[b];
+            if ((st % numS) > 0 && (st % numS) <= hlen) {
+                if (st >= numS) {
+                    int pos = (st % numS) - 1 + 1, len = 0, rpos = b;
+                    while (b < rlen && mapState[b] >= numS) { hpos[b] = DD_HPOS_INS; b++; len++; }
+                    if (out->n_indel < DDO_MAX_VAR) { out->indel_pos[out->n_indel] = pos; out->indel_len[out->n_indel] = len; out->indel_rpos[out->n_indel] = rpos; out->n_indel++; }
+                    b--;
+                } else {
+                    hpos[b] = st - 1;
+                    if (out->firstBase == -1) out->firstBase = st - 1; else if (st - 1 < out->firstBase) out->firstBase = st - 1;
+                    if (out->lastBase == -1) out->lastBase = st - 1; else if (st - 1 > out->lastBase) out->lastBase = st - 1;
+                    if (readseq[b] != hap[st - 1] && out->n_snp < DDO_MAX_VAR) { out->snp_pos[out->n_snp] = st - 1; out->snp_rpos[out->n_snp] = b; out->n_snp++; }
+                    if (b < rlen - 1) {
+                        int ns = mapState[b + 1];
+                        if (ns < numS && ns - st > 1 && out->n_indel < DDO_MAX_VAR) {
+                            out->indel_pos[out->n_indel] = st; out->indel_len[out->n_indel] = -(ns - st - 1); out->indel_rpos[out->n_indel] = b; out->n_indel++;
+                        }
+                    }
+                }
+            } else {
+                if (st % numS == 0) hpos[b] = DD_HPOS_LO; else hpos[b] = DD_HPOS_RO;
+            }
+            b++;
+        }
+    }
+    free(logMatch); free(logMismatch); free(tr); free(trI); free(alpha); free(obs); free(bt); free(state); free(mapState);
+    return 0;
+}

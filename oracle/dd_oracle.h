@@ -25,6 +25,10 @@ int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, i
 /* a batch in the product's flat layout; windows [first_window, first_window+n_win) (n_win<0: all) */
 int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win);
 
+/* secondary path: ObservationModelS(hap, read, hapStart, params).align(HapHash(4, hap)) — Faster.cpp, Haplotype.hpp:315-384 */
+int ddo_pair_fast(const char *hap, int hlen, const char *readseq, const double *qual, int rlen,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, const dd_params *P, ddo_out *out, int *hpos);
+
 /* N1: S[w][h1*H+h2] = sum_r log(0.5)+addLogs(ll[h1][r], ll[h2][r]) (reference DInDel.cpp:3085-3091) */
 int ddo_pair_sums(const dd_batch *B, const double *ll, double *out);
 

@@ -64,3 +64,20 @@ def test_hapsize_error_status():
     p = capi.params_cli_defaults()
     o, _ = _oracle.pair("ACG", "ACGT", 0.999, 0.9999, 0, 0, p)     # maxLengthDel=5 > hapSize=3
     assert o.status == capi.DD_PAIR_HAPSIZE
+
+
+def test_faster_model_kat():
+    """ObservationModelS ("--faster", Faster.cpp) values of SURVEY §8(c): S1 under struct and CLI parameters, S2."""
+    import ctypes as C
+    import numpy as np
+    lib = _oracle.load()
+    n = 0
+    for case in KAT:
+        if "ll_fast" not in case:
+            continue
+        p = capi.dd_params.from_dict(case["params"])
+        o, hpos = _oracle.pair_fast(case["hap"], case["read"], case["q"], case["mapQual"], case["pos"], case["hapStart"], p)
+        assert o.ll == pytest.approx(case["ll_fast"], rel=1e-13, abs=0)
+        assert o.offHap == 0 and o.offHapHMQ == 0          # always false in this model (Faster.cpp:491, :529)
+        n += 1
+    assert n == 3
