@@ -59,18 +59,18 @@ def measured_traffic(n_pairs):
     return best
 
 
-def cpu_baseline(pb, params, seconds_target=15.0):
+def cpu_baseline(pb, params, seconds_target=15.0, faster=False):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
     from tests import _oracle
     threads = max(1, min(16, os.cpu_count() or 1))
     n_win = min(pb.n_windows, 2 * threads)          # calibration pass: every thread busy
     t0 = time.time()
-    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win)
+    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win, faster=faster)
     dt = time.time() - t0
     per_win = dt / n_win
     n_win = int(max(threads, min(pb.n_windows, seconds_target / max(per_win, 1e-9))))
     t0 = time.time()
-    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win)
+    _oracle.batch(params, pb, nthreads=threads, first_window=0, n_win=n_win, faster=faster)
     dt = time.time() - t0
     a = pb.a
     h1, r1 = int(a["win_hap_off"][n_win]), int(a["win_read_off"][n_win])
@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--host-api", action="store_true",
                     help="also time dd_compute_likelihoods (host pointers in/out: H2D + kernels + D2H) once and report it "
                          "as host_api; never used for `value`")
+    ap.add_argument("--faster", action="store_true",
+                    help="time the secondary --faster model (ObservationModelS, SURVEY row A13) instead of the headline path; "
+                         "the JSON line then names that model in `metric` and is not the BASELINE metric")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0 (checks the N>1 code path; "
                          "the number it prints is not a multi-GPU measurement)")
@@ -142,8 +145,10 @@ def main():
             src = dev.out[k].cpu() if args.rehearse else dev.out[k]
             dist.gather(src, gather_bufs[k] if rank == 0 else None, dst=0)
 
+    launch = dev.launch_faster if args.faster else dev.launch
+
     def step():
-        dev.launch()
+        launch()
         if world > 1:
             gather()
 
@@ -157,7 +162,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        dev.launch()
+        launch()
         ev[i][1].record()
         if world > 1:
             gather()
@@ -224,7 +229,13 @@ def main():
             out["host_api"] = {"seconds": dt, "cells_per_s": cells / dt, "windows_per_s": args.windows / dt,
                                "note": "dd_compute_likelihoods with host pointers: H2D of the batch, kernels, D2H of every output"}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pb, params)
+            out["cpu_baseline"] = cpu_baseline(pb, params, faster=args.faster)
+        if args.faster:
+            out["metric"] = "read-haplotype cells/s, --faster model (ObservationModelS)"
+            out["roofline"]["kernel"] = "dd_faster_kernel"
+            out["roofline"]["traffic"] = None
+            out["roofline"]["note"] = "k-mer voting + <=16-diagonal Viterbi: instruction-issue bound like the headline kernel"
+            del out["valu_fp64"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -18,7 +18,7 @@ c_u8p = C.POINTER(C.c_uint8)
 c_i16p = C.POINTER(C.c_int16)
 c_f64p = C.POINTER(C.c_double)
 
-DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 64
+DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 64
 
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
 DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS = 0, 1, 2, 3
@@ -97,7 +97,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
-           "dd_compute_likelihoods", "dd_release_cache", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -127,6 +127,8 @@ def load():
     lib.dd_batch_sizes.argtypes = [C.POINTER(dd_batch), C.POINTER(dd_sizes)]
     lib.dd_batch_offsets.argtypes = [C.POINTER(dd_batch), c_i64p, c_i64p, c_i64p]
     lib.dd_compute_likelihoods.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
+    lib.dd_compute_likelihoods_faster.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
+    lib.dd_launch_device_faster.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch), C.POINTER(dd_device_result), C.c_void_p]
     lib.dd_release_cache.restype = None
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]

@@ -410,6 +410,18 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
             dst[2 + k] = pinsert + log((1.0 - pOffFirst)) + logpIns;  // prior[i*numS+x], 1<=x<=hapSize
         }
     }
+    // --faster model: ObservationModelS::setupReadLikelihoods / SStateHMM constants — reference Faster.cpp:117-124, :300-352
+    out[TC_FAST + 0] = log(1.0 - p->pError);
+    out[TC_FAST + 1] = log(p->pError);
+    out[TC_FAST + 2] = log(1 - exp(-0.25));
+    out[TC_FAST + 3] = log(1.0 - 1e-10);
+    out[TC_FAST + 4] = log(1e-10);
+    for (int i = 0; i < n_mapq; i++) {
+        double mq = 1.0 - mapq_table[i];
+        if (-10.0 * log10(mq) > p->capMapQualFast) mq = pow(10.0, -p->capMapQualFast / 10.0);
+        out[T_MAPQF + 2 * i] = log(1.0 - mq);
+        out[T_MAPQF + 2 * i + 1] = log(mq);
+    }
     // homopolymer indel-error logs — reference ObservationModelFB.cpp:1683-1703
     for (int len = 0; len < DD_HP_TABLE; len++) {
         const double perr = hp_error(len < 1 ? 1 : len);
@@ -441,6 +453,57 @@ struct LenClass {
     bool run_onhap = true;
 };
 
+// 0: ObservationModelFBMaxErr (computeLikelihoods), 1: ObservationModelS (computeLikelihoodsFaster); set by the entry points
+static thread_local int g_model = 0;
+
+// --faster model: wave-private LDS only (vote histogram, read emissions + bases, back-pointer bytes, state path)
+static size_t lds_layout_fast(int max_hap_len, int max_read_len, int &waves, ddk::KernelArgs &A)
+{
+    uint32_t off = 0;
+    A.lds_off_A = off;   off = up16(off + 4u * (uint32_t)(max_hap_len + max_read_len));
+    A.lds_off_rdE = off; off = up16(off + 16u * (uint32_t)max_read_len);
+    A.lds_off_rdC = off; off = up16(off + (uint32_t)max_read_len);
+    A.lds_off_bt = off;  off = up16(off + 32u * (uint32_t)max_read_len);
+    A.lds_off_ms = off;  off = up16(off + 2u * (uint32_t)max_read_len);
+    A.lds_wave_bytes = off;
+    A.lds_shared_bytes = 0;
+    waves = DD_WAVES;
+    while (waves > 1 && (size_t)waves * off > (size_t)64 * 1024) waves >>= 1;    // <= 64 KB per workgroup keeps >= 2 workgroups per CU
+    return (size_t)waves * off;
+}
+
+static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::KernelArgs &A, void *stream, int hap_begin, int hap_end,
+                       int read_begin, int read_end, bool want_onhap)
+{
+    (void)p;
+    int waves = DD_WAVES;
+    const size_t lds = lds_layout_fast(b->max_hap_len, b->max_read_len, waves, A);
+    if (lds > (size_t)160 * 1024) return fail(DD_ERR_UNSUPPORTED, "shape exceeds the LDS tile of the --faster kernel");
+    const int64_t target_blocks = 8192;
+    int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    int64_t max_split = (avg_reads + waves - 1) / waves;
+    if (max_split < 1) max_split = 1;
+    int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
+    A.n_split = (int32_t)split;
+    A.item_begin = (int32_t)(hap_begin * split);
+    A.n_items = (int32_t)(hap_end * split);
+    A.read_begin = read_begin; A.read_end = read_end;
+    A.hap_list = nullptr; A.len_min = 0; A.len_max = 0x7fffffff;
+    int64_t grid = (int64_t)(hap_end - hap_begin) * split;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (grid > 0) {
+        if (grid > 65536) grid = 65536;            // workgroups stride over the items
+        g_last_launch[0] = 0; g_last_launch[1] = 0; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
+        g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes; g_last_launch[7] = 0;
+        HIP_TRY(ddk::launch_faster(A, (unsigned)grid, waves, lds, st));
+    }
+    if (want_onhap) HIP_TRY(ddk::launch_onhap(A, st));
+    return DD_SUCCESS;
+}
+
 static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes,
                         void *stream, int hap_begin, int hap_end, int read_begin, int read_end, const LenClass *lc = nullptr)
 {
@@ -466,6 +529,10 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
 #endif
     A.always_ro = getenv("DD_ALWAYS_RO") ? 1 : 0;
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid; A.maxMismatch = p->maxMismatch;
+    if (g_model == 1) {
+        if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
+        return launch_fast(p, b, A, stream, hap_begin, hap_end, read_begin, read_end, r->onHap && r->offHapHMQ);
+    }
     Plan pl;
     const int cls_hap = lc ? lc->max_hap_len : b->max_hap_len, cls_read = lc ? lc->max_read_len : b->max_read_len;
     rc = make_plan(p, cls_hap, cls_read, b->n_qual, pl, A);
@@ -513,7 +580,16 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
 
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
+    g_model = 0;
     return launch_range(p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
+}
+
+int dd_launch_device_faster(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *stream)
+{
+    g_model = 1;
+    const int rc = launch_range(p, b, r, nullptr, 0, stream, 0, -1, 0, 0);
+    g_model = 0;
+    return rc;
 }
 
 int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off)
@@ -580,7 +656,23 @@ int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int
     return DD_SUCCESS;
 }
 
+static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+
 int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device)
+{
+    g_model = 0;
+    return compute_likelihoods_impl(p, b, r, device);
+}
+
+int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_result *r, int device)
+{
+    g_model = 1;
+    const int rc = compute_likelihoods_impl(p, b, r, device);
+    g_model = 0;
+    return rc;
+}
+
+static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -671,11 +763,12 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
     db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
     db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
     db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
-    size_t ws_bytes = dd_workspace_bytes(p, &db);
+    size_t ws_bytes = g_model == 1 ? 0 : dd_workspace_bytes(p, &db);
     int n_classes = 0;
     for (auto &hc : hcls) {
         if (hc.haps.empty()) continue;
         n_classes++;
+        if (g_model == 1) continue;
         for (auto &rcl : rcls) {
             dd_device_batch tmp = db;
             tmp.max_hap_len = hc.max_hap; tmp.max_read_len = rcl.max_len;
@@ -683,7 +776,7 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
             if (w > ws_bytes) ws_bytes = w;
         }
     }
-    const bool single_class = (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
+    const bool single_class = g_model == 1 || (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
 
     // ---- device arena (cached per host thread) ----
     const size_t np = (size_t)sz.n_pairs;

@@ -19,10 +19,12 @@ enum {
     TC_NDEF = 7,  /* log(1-1e-5)                 :1679 */
     TC_BQT = 8,   /* checkBaseQualThreshold */
     TC_HMQ = 12,  /* 4 doubles: bMid prior for mapQual = 1-1e-10 (:1093): off/noins, off/ins, on/noins, on/ins */
+    TC_FAST = 16, /* --faster model (Faster.cpp:300-352): log(1-pError), log(pError), log(1-exp(-0.25)), log(1-1e-10), log(1e-10) */
     T_QUAL = 32,                          /* 4 per quality: eq, uq (:232-234), log10(1-q) (:1406), q */
     T_MAPQ = T_QUAL + 4 * DD_MAX_QUAL_TABLE, /* 4 per mapping quality: prior off/noins, off/ins, on/noins, on/ins (:296-303) */
     T_HP = T_MAPQ + 4 * DD_MAX_QUAL_TABLE,   /* 2 per run length: log(perr(len)), log(1-perr(len)) (ReadIndelErrorModel.hpp:36-50) */
-    T_END = T_HP + 2 * DD_HP_TABLE
+    T_MAPQF = T_HP + 2 * DD_HP_TABLE,         /* --faster: 2 per mapping quality: log(1-pOffFirst), log(pOffFirst) with capMapQualFast (Faster.cpp:117-124) */
+    T_END = T_MAPQF + 2 * DD_MAX_QUAL_TABLE
 };
 
 namespace ddk {
@@ -64,6 +66,7 @@ struct KernelArgs {
 
 hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
+hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */
 
 /* N1: per-window haplotype-pair read sums (genotype_kernel.hip) */
 struct PairSumArgs {

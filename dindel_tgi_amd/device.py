@@ -84,6 +84,15 @@ class DeviceBatch:
         if rc != 0:
             raise RuntimeError("dd_launch_device rc=%d: %s" % (rc, capi.last_error()))
 
+    def launch_faster(self, stream=None):
+        """The --faster model (ObservationModelS) on the same resident batch. Asynchronous."""
+        lib = capi.load()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        rc = lib.dd_launch_device_faster(C.byref(self.params), C.byref(self.db), C.byref(self.dr), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dd_launch_device_faster rc=%d: %s" % (rc, capi.last_error()))
+
     def results(self):
         """Host copies (numpy) of the outputs, trimmed to their logical lengths."""
         torch.cuda.synchronize(self.device)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 3
+#define DD_ABI_VERSION 4
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -170,7 +170,7 @@ void dd_release_cache(void);
 /* Table block built on the host with libm (emission logs per quality, bMid priors per mapping
  * quality, homopolymer indel-error logs, transition constants).  Returns number of doubles written
  * (<= DD_TABLE_DOUBLES); `out` is host memory that the caller copies to the device. */
-#define DD_TABLE_DOUBLES (32 + 4*DD_MAX_QUAL_TABLE + 4*DD_MAX_QUAL_TABLE + 2*DD_HP_TABLE + 64)
+#define DD_TABLE_DOUBLES (32 + 4*DD_MAX_QUAL_TABLE + 4*DD_MAX_QUAL_TABLE + 2*DD_HP_TABLE + 2*DD_MAX_QUAL_TABLE + 64)
 int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
                     const double *mapq_table, int n_mapq, double *out);
 
@@ -199,6 +199,17 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b);
  * Result pointers are DEVICE pointers.  Asynchronous; no allocation, no synchronisation. */
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- row A13: the --faster model ---------------------------------------------------------- */
+/* Same batch in, same result layout out, but each pair is scored by ObservationModelS(hap, read, hapStart,
+ * params).align(HapHash(4, hap)) — DetInDel::computeLikelihoodsFaster, reference DInDel.cpp:1790-1833
+ * (Faster.cpp:42-681, Haplotype.hpp:315-384).  That model fills ll, hpos, firstBase, lastBase and the coverage
+ * flags; offHap / offHapHMQ are always 0 (Faster.cpp:491,:529) and llOn, llOff, mLogBQ and the counters stay 0, as
+ * MLAlignment's constructor leaves them.  Params used: pError, pMut, maxLengthDel (size check only), padCover,
+ * capMapQualFast, maxMismatch.  status: DD_PAIR_HAPSIZE (`throw string("hapSize error.")`, Faster.cpp:47) or
+ * DD_PAIR_NAN for a read shorter than the 4-mer (`throw string("HapHash string too short")`, Haplotype.hpp:341). */
+int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+int dd_launch_device_faster(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *stream);
 
 /* ---- N1 (next row): read sums of the diploid genotype reduction --------------------------- */
 /* S[w][h1*H_w+h2] (h1<=h2) = sum over the window's reads, in order, of log(0.5)+addLogs(ll[h1][r], ll[h2][r])

@@ -405,7 +405,10 @@ int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, i
 
 /* Whole batch in the product's flat layout (include/dindel_hmm.h) — used by the GPU parity tests as
  * the comparator and by bench.py as the "port" CPU baseline.  Serial over pairs unless nthreads>1. */
-int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win)
+int ddo_pair_fast(const char *hap, int hlen, const char *readseq, const double *qual, int rlen,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, const dd_params *P, ddo_out *out, int *hpos);
+
+static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win, int model)
 {
     int64_t w;
     int64_t W = B->n_windows;
@@ -453,8 +456,15 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                 ddo_out o;
                 int64_t p = pair_off[w] + (int64_t)(h - h0) * Rn + (r - r0);
                 for (i = 0; i < L; i++) q[i] = B->qual_table[B->read_qidx[so + i]];
-                ddo_pair(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
-                         B->win_hap_start[w], B->read_flags[r] & 1, P, &o, hp);
+                if (model == 0)
+                    ddo_pair(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
+                             B->win_hap_start[w], B->read_flags[r] & 1, P, &o, hp);
+                else {
+                    ddo_pair_fast(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
+                                  B->win_hap_start[w], P, &o, hp);
+                    if (o.status != DD_PAIR_OK) { o.offHapHMQ = 1; o.status = (o.status == DD_PAIR_HAPSIZE) ? DD_PAIR_HAPSIZE : DD_PAIR_NAN; }
+                }
+                const int bad = (o.status == DD_PAIR_HAPSIZE) || (model == 1 && o.status != DD_PAIR_OK);
                 R->ll[p] = o.ll;
                 R->status[p] = o.status;
                 if (R->llOn) R->llOn[p] = o.llOn;
@@ -470,7 +480,7 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                 if (R->nMMRight) R->nMMRight[p] = (int16_t)o.nMMRight;
                 if (R->firstBase) R->firstBase[p] = (int16_t)o.firstBase;
                 if (R->lastBase) R->lastBase[p] = (int16_t)o.lastBase;
-                if (R->hpos && o.status != DD_PAIR_HAPSIZE) {
+                if (R->hpos && !bad) {
                     int16_t *dst = R->hpos + hpos_off[w] + (int64_t)(h - h0) * SL + (so - B->read_seq_off[r0]);
                     for (i = 0; i < L; i++) dst[i] = (int16_t)hp[i];
                 }
@@ -480,7 +490,7 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                     for (i = 0; i < nv; i++) {
                         int sR = B->hap_var[2 * (B->hap_var_off[h] + i)];
                         int eR = B->hap_var[2 * (B->hap_var_off[h] + i) + 1];
-                        R->var_covered[vb + i] = (o.status != DD_PAIR_HAPSIZE && o.firstBase + P->padCover <= sR && o.lastBase - P->padCover >= eR) ? 1 : 0;
+                        R->var_covered[vb + i] = (!bad && o.firstBase + P->padCover <= sR && o.lastBase - P->padCover >= eR) ? 1 : 0;
                     }
                 }
                 if (R->var_fcov && B->hap_var_flank && nv > 0) {
@@ -488,7 +498,7 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                      * :2011-2054 (INS); written with the reference's own set/loop structure (b < L: the reference's
                      * b <= L reads one past hpos) */
                     int64_t vb = vcbase + (int64_t)(B->hap_var_off[h] - B->hap_var_off[h0]) * Rn + (int64_t)(r - r0) * nv;
-                    int sel = (o.status != DD_PAIR_HAPSIZE && !o.offHapHMQ && o.numIndels == 0);
+                    int sel = (!bad && !o.offHapHMQ && o.numIndels == 0);
                     for (i = 0; i < nv; i++) {
                         const int32_t *fl = B->hap_var_flank + 3 * (size_t)(B->hap_var_off[h] + i);
                         int left = fl[0] - P->padCover, right = fl[1] + P->padCover, kind = fl[2];
@@ -500,6 +510,7 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                                 int hb = hp[bb];
                                 if (hb >= left && hb <= right) {
                                     if (!cset[hb - left]) { cset[hb - left] = 1; csize++; }
+                                    if (hb < 0) continue;   /* sentinel in range (left < 0): the reference reads seq[-1..] here, undefined */
                                     if (kind == 1) { if (hs[hb] != 'N' && hs[hb] != B->read_seq[so + bb]) nmm++; }
                                     else { if (hs[hb] != B->read_seq[so + bb]) nmm++; }
                                 }
@@ -516,7 +527,7 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
                         R->var_fcov[vb + i] = (uint8_t)cov;
                     }
                 }
-                if (R->onHap && o.status != DD_PAIR_HAPSIZE && !o.offHapHMQ) R->onHap[r] = 1;
+                if (R->onHap && !bad && !o.offHapHMQ) R->onHap[r] = 1;
             }
         }
         free(q);
@@ -524,6 +535,17 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
     }
     free(pair_off); free(hpos_off); free(vc_off);
     return 0;
+}
+
+int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win)
+{
+    return batch_impl(P, B, R, nthreads, first_window, n_win, 0);
+}
+
+/* DetInDel::computeLikelihoodsFaster (DInDel.cpp:1790-1833) over the same flat layout */
+int ddo_batch_fast(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win)
+{
+    return batch_impl(P, B, R, nthreads, first_window, n_win, 1);
 }
 
 /* ---- N1: read sums of the diploid genotype reduction (reference DInDel.cpp:3085-3091, Utils.hpp:29-38) ---- */

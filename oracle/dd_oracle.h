@@ -29,6 +29,9 @@ int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads,
 int ddo_pair_fast(const char *hap, int hlen, const char *readseq, const double *qual, int rlen,
                   double mapQual, uint32_t readStartU32, uint32_t hapStart, const dd_params *P, ddo_out *out, int *hpos);
 
+/* the same for a batch (DetInDel::computeLikelihoodsFaster, DInDel.cpp:1790-1833) */
+int ddo_batch_fast(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win);
+
 /* N1: S[w][h1*H+h2] = sum_r log(0.5)+addLogs(ll[h1][r], ll[h2][r]) (reference DInDel.cpp:3085-3091) */
 int ddo_pair_sums(const dd_batch *B, const double *ll, double *out);
 

@@ -45,6 +45,7 @@ def load():
         _lib.ddo_pair_sums.argtypes = [C.POINTER(capi.dd_batch), capi.c_f64p, capi.c_f64p]
         _lib.ddo_batch.argtypes = [C.POINTER(capi.dd_params), C.POINTER(capi.dd_batch), C.POINTER(capi.dd_result),
                                    C.c_int, C.c_int64, C.c_int64]
+        _lib.ddo_batch_fast.argtypes = _lib.ddo_batch.argtypes
     return _lib
 
 
@@ -73,12 +74,14 @@ def pair_fast(hap, read, qual, mapQual, read_start, hap_start, params):
     return o, list(hp)[:L]
 
 
-def batch(params, pb, nthreads=1, first_window=0, n_win=-1):
-    """Whole PackedBatch through the oracle -> dict of numpy result arrays (same layout as the product)."""
+def batch(params, pb, nthreads=1, first_window=0, n_win=-1, faster=False):
+    """Whole PackedBatch through the oracle -> dict of numpy result arrays (same layout as the product).
+    faster=True: the ObservationModelS restatement (computeLikelihoodsFaster)."""
     from dindel_tgi_amd.batch import alloc_result
     lib = load()
     arrs, res = alloc_result(pb)
     b = pb.ctypes_batch()
-    rc = lib.ddo_batch(C.byref(params), C.byref(b), C.byref(res), nthreads, first_window, n_win)
+    fn = lib.ddo_batch_fast if faster else lib.ddo_batch
+    rc = fn(C.byref(params), C.byref(b), C.byref(res), nthreads, first_window, n_win)
     assert rc == 0
     return arrs
