@@ -456,32 +456,64 @@ struct LenClass {
 // 0: ObservationModelFBMaxErr (computeLikelihoods), 1: ObservationModelS (computeLikelihoodsFaster); set by the entry points
 static thread_local int g_model = 0;
 
-// --faster model: wave-private LDS only (vote histogram, read emissions + bases, back-pointer bytes, state path)
-static size_t lds_layout_fast(int max_hap_len, int max_read_len, int &waves, ddk::KernelArgs &A)
+// --faster model LDS: block-shared haplotype index + per-pair areas (layout in faster_kernel.hip's header)
+static size_t lds_layout_fast(int max_hap_len, int max_read_len, int n_qual, int &waves, int &groups, ddk::KernelArgs &A)
 {
     uint32_t off = 0;
-    A.lds_off_A = off;   off = up16(off + 4u * (uint32_t)(max_hap_len + max_read_len));
-    A.lds_off_rdE = off; off = up16(off + 16u * (uint32_t)max_read_len);
-    A.lds_off_rdC = off; off = up16(off + (uint32_t)max_read_len);
-    A.lds_off_bt = off;  off = up16(off + 32u * (uint32_t)max_read_len);
-    A.lds_off_ms = off;  off = up16(off + 2u * (uint32_t)max_read_len);
-    A.lds_wave_bytes = off;
-    A.lds_shared_bytes = 0;
-    waves = DD_WAVES;
-    while (waves > 1 && (size_t)waves * off > (size_t)64 * 1024) waves >>= 1;    // <= 64 KB per workgroup keeps >= 2 workgroups per CU
-    return (size_t)waves * off;
+    A.lds_off_E = off; off = up16(off + 16u * (uint32_t)(n_qual > 0 ? n_qual : 1));
+    A.lds_off_N = off; off = up16(off + (uint32_t)max_hap_len);
+    A.lds_off_Q = off; off = up16(off + 2u * 257u);
+    A.lds_off_C = off; off = up16(off + 2u * (uint32_t)max_hap_len);
+    A.lds_off_Y = off; off = up16(off + 4u * 256u);
+    A.lds_off_rdE = off; off = up16(off + 6u * 256u);          // FAST_CHUNK sort keys (u32) + ranks (u16)
+    A.lds_shared_bytes = off;
+    uint32_t po = 0;
+    A.lds_off_A = po;   po = up16(po + 4u * (uint32_t)((max_hap_len + max_read_len + 1) / 2 + 1));
+    A.lds_off_rdC = po; po = up16(po + 2u * (uint32_t)max_read_len);
+    A.lds_off_bt = po;  po = up16(po + 16u * (uint32_t)max_read_len);
+    A.lds_off_ms = A.lds_off_A;                  // the state path reuses the histogram bytes
+    A.lds_off_I = po;   po = up16(po + 256u);
+    A.lds_off_rdQ = po; po = up16(po + 64u);
+    A.lds_wave_bytes = po;                       // bytes per PAIR area
+    const size_t cap = (size_t)160 * 1024;
+    // pair areas per wavefront: one per concurrent pair, plus a dummy for the idle 16-lane groups when fewer than 4 fit
+    auto areas = [](int gq) { return gq < 4 ? gq + 1 : 4; };
+    groups = 4;
+    if (const char *e = getenv("DD_FAST_GROUPS")) {             // tests: exercise the fewer-pairs-per-wavefront geometry
+        const int gq = atoi(e);
+        if (gq == 1 || gq == 2) groups = gq;
+    }
+    while (groups > 1 && (size_t)off + (size_t)areas(groups) * po > cap) groups >>= 1;
+    // waves per workgroup: whatever keeps the most wavefronts resident per CU (ties: more waves share one haplotype index)
+    int best_w = 1, best_res = 0;
+    for (int wv = DD_WAVES; wv >= 1; wv--) {
+        const size_t bytes = (size_t)off + (size_t)wv * areas(groups) * po;
+        if (bytes > cap) continue;
+        int blocks = (int)(cap / bytes);
+        int res = blocks * wv;
+        if (res > 8) res = 8;                    // the kernel is built for 2 waves per SIMD
+        if (res > best_res) { best_res = res; best_w = wv; }
+    }
+    waves = best_w;
+    if (const char *e = getenv("DD_FAST_WAVES")) {              // A/B only
+        const int wv = atoi(e);
+        if (wv >= 1 && wv <= DD_WAVES && (size_t)off + (size_t)wv * areas(groups) * po <= cap) waves = wv;
+    }
+    return (size_t)off + (size_t)waves * areas(groups) * po;
 }
 
 static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::KernelArgs &A, void *stream, int hap_begin, int hap_end,
                        int read_begin, int read_end, bool want_onhap)
 {
     (void)p;
-    int waves = DD_WAVES;
-    const size_t lds = lds_layout_fast(b->max_hap_len, b->max_read_len, waves, A);
+    int waves = DD_WAVES, groups = 4;
+    const size_t lds = lds_layout_fast(b->max_hap_len, b->max_read_len, b->n_qual, waves, groups, A);
     if (lds > (size_t)160 * 1024) return fail(DD_ERR_UNSUPPORTED, "shape exceeds the LDS tile of the --faster kernel");
+    A.n_qual = b->n_qual;
+    A.fast_groups = groups;
     const int64_t target_blocks = 8192;
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
-    int64_t max_split = (avg_reads + waves - 1) / waves;
+    int64_t max_split = (avg_reads + waves * groups - 1) / (waves * groups);
     if (max_split < 1) max_split = 1;
     int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
     if (split > max_split) split = max_split;
@@ -496,7 +528,7 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (grid > 0) {
         if (grid > 65536) grid = 65536;            // workgroups stride over the items
-        g_last_launch[0] = 0; g_last_launch[1] = 0; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
+        g_last_launch[0] = groups; g_last_launch[1] = 0; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
         g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes; g_last_launch[7] = 0;
         HIP_TRY(ddk::launch_faster(A, (unsigned)grid, waves, lds, st));
     }

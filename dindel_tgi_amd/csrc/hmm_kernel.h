@@ -56,6 +56,7 @@ struct KernelArgs {
     const int32_t *hap_list;             /* length-class launches: haplotype of item i is hap_list[i / n_split]; NULL = identity */
     int32_t len_min, len_max;            /* length-class launches: only reads with len_min <= L <= len_max */
     int32_t run_onhap;
+    int32_t fast_groups;                 /* --faster kernel: pairs a wavefront works on at a time (4, 2 or 1; LDS-limited) */
     void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */

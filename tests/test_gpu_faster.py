@@ -75,6 +75,9 @@ def test_faster_kat_through_c_abi(lib, case):
     dict(n=3, H=4, R=21, L=100, hap_len=170, seed=105, mixed_quals=True, sub_rate=0.03),
     dict(n=2, H=3, R=9, L=250, hap_len=400, seed=106, mixed_quals=True, sub_rate=0.02),
     dict(n=2, H=3, R=12, L=70, hap_len=50, seed=107, mixed_quals=True),                 # reads longer than the haplotype
+    dict(n=2, H=2, R=600, L=40, hap_len=60, seed=108, mixed_quals=True, vary_read_len=True),   # > 2 chunks of 256 reads per window
+    dict(n=1, H=2, R=7, L=700, hap_len=760, seed=109, mixed_quals=True, sub_rate=0.01),  # pair area too large for 4 pairs per wavefront
+    dict(n=1, H=2, R=5, L=1024, hap_len=766, seed=110, mixed_quals=True, sub_rate=0.3),  # maximum shape; alphas reach the -1000 floor
 ])
 @pytest.mark.parametrize("defaults", ["cli", "struct"])
 def test_faster_parity_synthetic(lib, cfg, defaults):
@@ -117,6 +120,19 @@ def test_faster_repeats_n_bases_and_short_reads(lib):
         want = _oracle.batch(p, pb, nthreads=8, faster=True)
         assert (want["status"][:pb.n_pairs] != 0).any() and (want["status"][:pb.n_pairs] == 0).any()
         assert_same_faster(run_faster(lib, p, pb), want, pb)
+
+
+@pytest.mark.parametrize("groups", ["1", "2"])
+def test_faster_fewer_pairs_per_wavefront(lib, groups, monkeypatch):
+    """Geometry used when four pair areas do not fit in LDS (not reachable at today's DD_MAX_* limits): forced here."""
+    monkeypatch.setenv("DD_FAST_GROUPS", groups)
+    pb = synth.generate(3, H=3, R=21, L=60, hap_len=80, seed=150 + int(groups), mixed_quals=True, vary_read_len=True)
+    p = capi.params_cli_defaults()
+    got = run_faster(lib, p, pb)
+    ll = np.zeros(8, np.int32)
+    lib.dd_last_launch(C.byref((C.c_int32 * 8).from_buffer(ll)))
+    assert int(ll[0]) == int(groups)
+    assert_same_faster(got, _oracle.batch(p, pb, nthreads=8, faster=True), pb)
 
 
 def test_faster_device_pointer_path(lib):
