@@ -104,6 +104,67 @@ void LikelihoodEngine::rebuildAlignment(const Haplotype &hap, const Read &read, 
         ml.hapSNPCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
 }
 
+void LikelihoodEngine::rebuildAlignmentFaster(const Haplotype &hap, const Read &read, const int16_t *hp,
+                                              const ObservationModelParameters &p, MLAlignment &ml)
+{
+    const int L = int(read.size()), Hs = int(hap.size());
+    ml.align = std::string(Hs, 'R');
+    ml.indels.clear(); ml.snps.clear(); ml.hapIndelCovered.clear(); ml.hapSNPCovered.clear();
+    ml.hpos.assign(hp, hp + L);
+    ml.firstBase = -1; ml.lastBase = -1;
+    int lhp = 1;                                       // Faster.cpp:553
+    int b = 0;
+    while (b < L) {
+        const int h = hp[b];
+        if (h == MLAlignment::INS) {                   // Faster.cpp:606-621
+            const int rpos = b;
+            int len = 0;
+            while (b < L && hp[b] == MLAlignment::INS) { b++; len++; }
+            const int pos = lhp;
+            ml.indels[pos] = AlignedVariant(std::string("+").append(read.seq.seq.substr(rpos, len)), pos, pos, rpos, b - 1);
+            continue;
+        }
+        if (h >= 0) {
+            lhp = h + 1;
+            if (ml.firstBase == -1) ml.firstBase = h; else if (h < ml.firstBase) ml.firstBase = h;
+            if (ml.lastBase == -1) ml.lastBase = h; else if (h > ml.lastBase) ml.lastBase = h;
+            if (read.seq[b] != hap.seq[h]) {           // :631-643
+                std::string snp;
+                snp += hap.seq[h];
+                snp.append("=>");
+                snp += read.seq[b];
+                ml.snps[h] = AlignedVariant(snp, h, h, b, b);
+                ml.align[h] = read.seq[b];
+            }
+            if (b < L - 1 && hp[b + 1] >= 0 && hp[b + 1] - h > 1) {     // :645-661: next state on a later base
+                const int pos = h + 1, len = hp[b + 1] - h - 1;
+                for (int y = pos; y < pos + len && y < Hs; y++) ml.align[y] = 'D';
+                ml.indels[pos] = AlignedVariant(std::string("-").append(hap.seq.substr(pos, len)), pos, pos + len - 1, b, b + 1);
+            }
+        }
+        b++;
+    }
+    for (std::map<int, AlignedVariant>::const_iterator it = hap.indels.begin(); it != hap.indels.end(); ++it)
+        ml.hapIndelCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
+    for (std::map<int, AlignedVariant>::const_iterator it = hap.snps.begin(); it != hap.snps.end(); ++it)
+        ml.hapSNPCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
+}
+
+void LikelihoodEngine::computeLikelihoodsFaster(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
+                                                std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos,
+                                                uint32_t rightPos, std::vector<int> &onHap)
+{
+    std::vector<WindowJob> jobs(1);
+    jobs[0].haps = &haps; jobs[0].reads = &reads; jobs[0].leftPos = leftPos; jobs[0].rightPos = rightPos;
+    jobs[0].liks = &liks; jobs[0].onHap = &onHap;
+    runBatch(jobs, true);
+    if (!jobs[0].error.empty()) throw jobs[0].error;
+}
+
+void LikelihoodEngine::computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs) { runBatch(jobs, true); }
+
+void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs) { runBatch(jobs, false); }
+
 void LikelihoodEngine::computeLikelihoods(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
                                           std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos,
                                           uint32_t rightPos, std::vector<int> &onHap)
@@ -115,7 +176,7 @@ void LikelihoodEngine::computeLikelihoods(const std::vector<Haplotype> &haps, co
     if (!jobs[0].error.empty()) throw jobs[0].error;
 }
 
-void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
+void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
 {
     const int W = int(jobs.size());
     // ---- pack (CSR) ----
@@ -194,8 +255,8 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
     Rz.var_fcov = fcov.data();
     const dd_params P = to_abi(params);
     if (sz.n_pairs > 0) {
-        const int rc = dd_compute_likelihoods(&P, &B, &Rz, device_);
-        if (rc != DD_SUCCESS) throw std::string("dd_compute_likelihoods: ") + dd_last_error();
+        const int rc = faster ? dd_compute_likelihoods_faster(&P, &B, &Rz, device_) : dd_compute_likelihoods(&P, &B, &Rz, device_);
+        if (rc != DD_SUCCESS) throw std::string(faster ? "dd_compute_likelihoods_faster: " : "dd_compute_likelihoods: ") + dd_last_error();
     }
 
     // ---- unpack into liks[hidx][r] / onHap, window by window, in order ----
@@ -209,13 +270,15 @@ void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs)
         for (size_t h = 0; h < H && J.error.empty(); h++) {
             for (size_t r = 0; r < Rn; r++) {
                 const int64_t p = pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
-                if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47
+                if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47, Faster.cpp:47
+                if (faster && status[p] != DD_PAIR_OK) { J.error = "HapHash string too short"; break; }   // Haplotype.hpp:341
                 MLAlignment &ml = (*J.liks)[h][r];
                 const int16_t *hp = hpos.data() + hpos_off[w] + int64_t(h) * SL + (read_seq_off[r0 + r] - read_seq_off[r0]);
-                rebuildAlignment((*J.haps)[h], (*J.reads)[r], hp, params, ml);
+                if (faster) rebuildAlignmentFaster((*J.haps)[h], (*J.reads)[r], hp, params, ml);
+                else rebuildAlignment((*J.haps)[h], (*J.reads)[r], hp, params, ml);
                 ml.ll = ll[p]; ml.llOn = llOn[p]; ml.llOff = llOff[p];
                 ml.offHap = offHap[p] != 0; ml.offHapHMQ = offHapHMQ[p] != 0;
-                ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
+                if (!faster) ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
                 {   // per haplotype-indel coverage flags of filterHaplotypes, in hap.indels map order (first nvI of the hap's list)
                     const Haplotype &Hh = (*J.haps)[h];
                     const int g = win_hap_off[w] + int(h);

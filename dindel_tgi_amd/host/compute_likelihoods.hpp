@@ -44,6 +44,14 @@ public:
     // thrown gets its message in WindowJob::error (the caller turns it into the "skipped" row, DInDel.cpp:1361-1408).
     void computeLikelihoodsBatch(std::vector<WindowJob> &jobs);
 
+    // DetInDel::computeLikelihoodsFaster (reference DInDel.cpp:1790-1833): the --faster model, ObservationModelS.
+    // Throws std::string("hapSize error.") (Faster.cpp:47) or std::string("HapHash string too short")
+    // (Haplotype.hpp:341, read shorter than the 4-mer); no likelihood checks, as in the reference.
+    void computeLikelihoodsFaster(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
+                                  std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos, uint32_t rightPos,
+                                  std::vector<int> &onHap);
+    void computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs);
+
     void setThrowOnPositiveLikelihood(bool v) { throwOnPositive_ = v; }
 
     // ObservationModelFBMax::reportVariants (ObservationModelFB.cpp:1351-1475) from the device's hpos: fills
@@ -51,7 +59,14 @@ public:
     static void rebuildAlignment(const Haplotype &hap, const Read &read, const int16_t *hpos,
                                  const ObservationModelParameters &p, MLAlignment &ml);
 
+    // ObservationModelS::reportVariants (Faster.cpp:579-681) from the device's hpos.  The position of an insertion is
+    // one past the last on-haplotype base before it (Faster.cpp:552-571); bases the model parks on the last haplotype
+    // base because they lie right of the haplotype are indistinguishable from it in hpos and count as that base here.
+    static void rebuildAlignmentFaster(const Haplotype &hap, const Read &read, const int16_t *hpos,
+                                       const ObservationModelParameters &p, MLAlignment &ml);
+
 private:
+    void runBatch(std::vector<WindowJob> &jobs, bool faster);
     int device_;
     bool throwOnPositive_;
 };

@@ -42,6 +42,7 @@ static ObservationModelParameters make_params(const double *pd, const int *pi)
 {
     ObservationModelParameters p;
     p.pError = pd[0]; p.pMut = pd[1]; p.pFirstgLO = pd[2]; p.mapQualThreshold = pd[3]; p.checkBaseQualThreshold = pd[4];
+    p.capMapQualFast = pd[5];
     p.maxLengthDel = p.maxLengthIndel = pi[0]; p.padCover = pi[1]; p.bMid = pi[2];
     return p;
 }
@@ -79,9 +80,9 @@ int ddh_rebuild_json(const char *hap, const char *read, const double *qual, cons
 
 // GPU: one window through LikelihoodEngine::computeLikelihoods.  haps / reads are '\n'-joined strings,
 // quals one double per read base (concatenated), mapq / start / unmapped per read.
-int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
-                            const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
-                            int device, char *out, int cap)
+static int compute_window_json(bool faster, const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
+                               const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
+                               int device, char *out, int cap)
 {
     try {
         std::vector<Haplotype> haps;
@@ -106,7 +107,8 @@ int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const dou
         eng.setThrowOnPositiveLikelihood(true);
         std::vector<std::vector<MLAlignment> > liks;
         std::vector<int> onHap;
-        eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        if (faster) eng.computeLikelihoodsFaster(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        else eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
         std::ostringstream os;
         os << "{\"onHap\":[";
         for (size_t i = 0; i < onHap.size(); i++) os << (i ? "," : "") << onHap[i];
@@ -121,6 +123,21 @@ int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const dou
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
     }
+}
+
+int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
+                            const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
+                            int device, char *out, int cap)
+{
+    return compute_window_json(false, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap);
+}
+
+// the same through LikelihoodEngine::computeLikelihoodsFaster (--faster model)
+int ddh_compute_window_faster_json(const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
+                                   const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
+                                   int device, char *out, int cap)
+{
+    return compute_window_json(true, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap);
 }
 
 // N1 host step: returns {max_indel_pair, max_noindel_pair, max_ll_indel, max_ll_noindel, qual} or -1 on the
@@ -182,9 +199,11 @@ int ddh_filter_window_json(const char *haps_nl, const int *hap_vars, const char 
         LikelihoodEngine eng(P, device);
         std::vector<std::vector<MLAlignment> > liks;
         std::vector<int> onHap, filtered;
-        eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        const bool faster = (doFilter & 2) != 0;          // bit 1: use the --faster model for the likelihoods
+        if (faster) eng.computeLikelihoodsFaster(haps, reads, liks, leftPos, leftPos + 1, onHap);
+        else eng.computeLikelihoods(haps, reads, liks, leftPos, leftPos + 1, onHap);
         std::map<VariantKey, VariantCoverage> cov;
-        filterHaplotypes(haps, reads, liks, filtered, cov, doFilter != 0);
+        filterHaplotypes(haps, reads, liks, filtered, cov, (doFilter & 1) != 0);
         std::ostringstream os;
         os << "{\"filtered\":[";
         for (size_t i = 0; i < filtered.size(); i++) os << (i ? "," : "") << filtered[i];

@@ -26,7 +26,7 @@ def load():
 
 
 def _params(p):
-    pd = (C.c_double * 5)(p.pError, p.pMut, p.pFirstgLO, p.mapQualThreshold, p.checkBaseQualThreshold)
+    pd = (C.c_double * 6)(p.pError, p.pMut, p.pFirstgLO, p.mapQualThreshold, p.checkBaseQualThreshold, p.capMapQualFast)
     pi = (C.c_int * 3)(p.maxLengthDel, p.padCover, p.bMid)
     return pd, pi
 
@@ -46,7 +46,7 @@ def rebuild(hap, read, qual, hpos, params, hap_indels=()):
     return json.loads(out.value.decode())
 
 
-def compute_window(haps, reads, quals, mapq, pos_first, unmapped, left_pos, params, device=0):
+def compute_window(haps, reads, quals, mapq, pos_first, unmapped, left_pos, params, device=0, faster=False):
     lib = load()
     q = np.ascontiguousarray(np.concatenate([np.broadcast_to(np.asarray(x, np.float64), (len(r),)) for x, r in zip(quals, reads)]))
     mq = np.asarray(mapq, np.float64)
@@ -54,14 +54,15 @@ def compute_window(haps, reads, quals, mapq, pos_first, unmapped, left_pos, para
     um = np.asarray(unmapped, np.int32)
     pd, pi = _params(params)
     out = C.create_string_buffer(1 << 24)
-    n = lib.ddh_compute_window_json("\n".join(haps).encode(), "\n".join(reads).encode(), q.ctypes.data_as(capi.c_f64p),
+    fn = lib.ddh_compute_window_faster_json if faster else lib.ddh_compute_window_json
+    n = fn("\n".join(haps).encode(), "\n".join(reads).encode(), q.ctypes.data_as(capi.c_f64p),
                                     mq.ctypes.data_as(capi.c_f64p), pf.ctypes.data_as(capi.c_f64p),
                                     um.ctypes.data_as(capi.c_i32p), C.c_uint(left_pos & 0xFFFFFFFF), pd, pi, device, out, len(out))
     assert n > 0, n
     return json.loads(out.value.decode())
 
 
-def filter_window(haps, hap_vars, reads, quals, mapq, pos_first, rflags, left_pos, params, do_filter=True, device=0):
+def filter_window(haps, hap_vars, reads, quals, mapq, pos_first, rflags, left_pos, params, do_filter=True, device=0, faster=False):
     """computeLikelihoods + filterHaplotypes through the C++ host adapter.  hap_vars: per hap list of
     (key, kind, leftFlankRead, rightFlankRead)."""
     lib = load()
@@ -78,6 +79,6 @@ def filter_window(haps, hap_vars, reads, quals, mapq, pos_first, rflags, left_po
     n = lib.ddh_filter_window_json("\n".join(haps).encode(), hv.ctypes.data_as(capi.c_i32p), "\n".join(reads).encode(),
                                    q.ctypes.data_as(capi.c_f64p), mq.ctypes.data_as(capi.c_f64p), pf.ctypes.data_as(capi.c_f64p),
                                    rf.ctypes.data_as(capi.c_i32p), C.c_uint(left_pos & 0xFFFFFFFF), pd, pi, params.maxMismatch,
-                                   1 if do_filter else 0, device, out, len(out))
+                                   (1 if do_filter else 0) | (2 if faster else 0), device, out, len(out))
     assert n > 0, n
     return json.loads(out.value.decode())

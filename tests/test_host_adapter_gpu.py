@@ -127,3 +127,50 @@ def test_engine_filter_haplotypes_matches_reference_loop():
     assert res["filtered"] == filtered
     assert res["coverage"] == want_cov
     assert sum(c[2] + c[3] for c in want_cov) > 0
+
+
+# ---------------- --faster model: LikelihoodEngine::computeLikelihoodsFaster (DInDel.cpp:1790-1833) ----------------
+@pytest.mark.parametrize("case", [c for c in KAT if "ll_fast" in c], ids=lambda c: c["name"])
+def test_engine_faster_on_kat(case):
+    p = capi.dd_params.from_dict(case["params"])
+    res = _host.compute_window([case["hap"]], [case["read"]], [case["q"]], [case["mapQual"]], [float(case["pos"])], [0],
+                               case["hapStart"], p, faster=True)
+    ml = res["liks"][0][0]
+    assert ml["ll"] == pytest.approx(case["ll_fast"], rel=1e-14, abs=0)
+    assert (ml["offHap"], ml["offHapHMQ"]) == (0, 0) and res["onHap"] == [1]
+
+
+def test_engine_faster_window_matches_oracle():
+    """ll, hpos, firstBase/lastBase and the variants ObservationModelS::reportVariants lists (Faster.cpp:579-681)."""
+    H = "ACGTTGCATGCCGATAGGCTTAACCGGTTTTTTACGATCGATGCAAGTCCGTAGGATCCATTAGCAGGATACCAGTTAG"
+    haps = [H, H[:25] + H[28:], H[:30] + "GGAT" + H[30:]]
+    reads = [H[10:50], H[5:25] + H[28:55], "GTCA" * 9 + "GT", H[20:30] + "GGAT" + H[30:60], "TTGACCA" + H[0:35], H[40:] + "ACGTACG",
+             H[12:30] + "T" + H[31:52]]
+    quals = [0.999, 0.99, 0.999, 0.9999, 0.999, 0.999, 0.9999]
+    mapq = [0.9999, 0.999, 0.9, 0.9999, 0.99, 0.9999, 0.999]
+    pos = [1010.0, 1005.0, 1010.0, 1020.0, 993.0, 1040.0, 1012.0]
+    for p in (capi.params_cli_defaults(), capi.params_struct_defaults()):
+        res = _host.compute_window(haps, reads, quals, mapq, pos, [0] * len(reads), 1000, p, faster=True)
+        assert res["onHap"] == [1] * len(reads)
+        n_indel = 0
+        for h, hap in enumerate(haps):
+            for r, read in enumerate(reads):
+                o, hpos = _oracle.pair_fast(hap, read, quals[r], mapq[r], int(pos[r]), 1000, p)
+                ml = res["liks"][h][r]
+                assert ml["ll"] == o.ll and ml["hpos"] == hpos
+                assert (ml["firstBase"], ml["lastBase"]) == (o.firstBase, o.lastBase)
+                assert (ml["offHap"], ml["offHapHMQ"], ml["numIndels"], ml["nBQT"]) == (0, 0, 0, 0)
+                want = sorted((o.indel_pos[i], o.indel_len[i], o.indel_rpos[i]) for i in range(o.n_indel))
+                got = sorted((i[0], (len(i[1]) - 1) * (1 if i[1][0] == "+" else -1), i[4]) for i in ml["indels"])
+                # several events at one haplotype position overwrite each other in the reference's map: compare by position
+                assert {w[0]: w for w in want} == {g[0]: g for g in got}
+                assert sorted(s[0] for s in ml["snps"]) == sorted(set(o.snp_pos[i] for i in range(o.n_snp)))
+                n_indel += o.n_indel
+        assert n_indel > 0
+
+
+def test_engine_faster_throws_reference_strings():
+    p = capi.params_cli_defaults()
+    assert _host.compute_window(["ACG"], ["ACGT"], [0.999], [0.9999], [0.0], [0], 0, p, faster=True) == {"throw": "hapSize error."}
+    assert _host.compute_window(["ACGTACGTACGT"], ["ACG"], [0.999], [0.9999], [0.0], [0], 0, p, faster=True) == \
+        {"throw": "HapHash string too short"}
