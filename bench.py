@@ -42,7 +42,7 @@ def algorithmic_bytes_per_pair(L, Hs, R):
     return 4.0 * L + 48.0 + float(Hs) / R
 
 
-def measured_traffic(n_pairs):
+def measured_traffic(n_pairs, kernel_sub="dd_hmm_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, profiles/r*/..._pmc.json) — only when the profiled launch had
     exactly this many pairs; otherwise None.  bench.py itself cannot collect PMC counters."""
@@ -52,6 +52,8 @@ def measured_traffic(n_pairs):
         try:
             d = json.load(open(f))
         except Exception:
+            continue
+        if kernel_sub not in json.dumps(d.get("kernel", "")):
             continue
         for cfg in d.values():
             if isinstance(cfg, dict) and cfg.get("pairs_per_launch") == n_pairs and "hbm_bytes_raw" in cfg:
@@ -233,7 +235,9 @@ def main():
         if args.faster:
             out["metric"] = "read-haplotype cells/s, --faster model (ObservationModelS)"
             out["roofline"]["kernel"] = "dd_faster_kernel"
-            out["roofline"]["traffic"] = None
+            tr = measured_traffic(n_pairs, "dd_faster_kernel") or {}
+            out["roofline"]["traffic"] = tr.get("bytes")
+            out["roofline"]["traffic_source"] = tr.get("source")
             out["roofline"]["note"] = "k-mer voting + <=16-diagonal Viterbi: instruction-issue bound like the headline kernel"
             del out["valu_fp64"]
         print(json.dumps(out))

@@ -166,6 +166,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int rr = r0 + cb + t;
             const int L = P.read_seq_off[rr + 1] - P.read_seq_off[rr];
             skey[t] = ((uint32_t)fast_bmid(hapStart, hlen, P.read_start[rr], L) << 11) | (uint32_t)(L > 0 ? ((L - 1) & 2047) : 0);
+            // Outputs this model leaves at MLAlignment's defaults, written here coalesced over the chunk's pairs instead of
+            // pair by pair from the group leaders (which go in bMid order).  A pair the reference throws for is finished here.
+            const int64_t pair = pair_base + cb + t;
+            const bool good = hap_ok && L >= 4;
+            if (P.out.llOn) P.out.llOn[pair] = 0.0;
+            if (P.out.llOff) P.out.llOff[pair] = 0.0;
+            if (P.out.mLogBQ) P.out.mLogBQ[pair] = 0.0;
+            if (P.out.offHap) P.out.offHap[pair] = 0;                          // always false (:491)
+            if (P.out.offHapHMQ) P.out.offHapHMQ[pair] = good ? 0 : 1;         // always false (:529); a thrown pair never counts as on-haplotype
+            if (P.out.numIndels) P.out.numIndels[pair] = 0;
+            if (P.out.numMismatch) P.out.numMismatch[pair] = 0;
+            if (P.out.nBQT) P.out.nBQT[pair] = 0;
+            if (P.out.nmmBQT) P.out.nmmBQT[pair] = 0;
+            if (P.out.nMMLeft) P.out.nMMLeft[pair] = 0;
+            if (P.out.nMMRight) P.out.nMMRight[pair] = 0;
+            if (!good) {
+                P.out.status[pair] = hap_ok ? DD_PAIR_NAN : DD_PAIR_HAPSIZE;
+                P.out.ll[pair] = 0.0;
+                if (nv > 0) {
+                    const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)(cb + t) * nv;
+                    for (int i = 0; i < nv; i++) {
+                        if (P.out.var_covered) P.out.var_covered[vb + i] = 0;
+                        if (P.out.var_fcov) P.out.var_fcov[vb + i] = 0;
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int t = tid; t < nch; t += blockDim.x) {
@@ -187,20 +213,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int Lraw = P.read_seq_off[rr + 1] - so;
             const bool good = valid && hap_ok && Lraw >= 4;
             const int L = good ? Lraw : 0;
-            if (valid && !good) {                                   // the reference throws for this pair
-                if (l16 == 0) {
-                    P.out.status[pair] = hap_ok ? DD_PAIR_NAN : DD_PAIR_HAPSIZE;
-                    P.out.ll[pair] = 0.0;
-                    if (P.out.offHapHMQ) P.out.offHapHMQ[pair] = 1; // never counts as on-haplotype
-                }
-                if (nv > 0) {
-                    const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
-                    for (int i = l16; i < nv; i += 16) {
-                        if (P.out.var_covered) P.out.var_covered[vb + i] = 0;
-                        if (P.out.var_fcov) P.out.var_fcov[vb + i] = 0;
-                    }
-                }
-            }
             if (__ballot(good) == 0) continue;
 
             const int bMid = good ? fast_bmid(hapStart, hlen, P.read_start[rr], L) : 0;
@@ -289,6 +301,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             double leftN = 0.0, leftI = 0.0;
             auto passes = [&](auto nsc) {
                 constexpr int NS = decltype(nsc)::value;
+                int lv = l16;                               // opaque copy: keeps the per-source selects below from being hoisted
+                asm volatile("" : "+v"(lv));                // out of the read loop as 2 x 16 spilled lane constants
             // from left to bMid (:373-416)
             {
                 double tA[NS], tB[NS];
@@ -297,9 +311,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int cs = 0; cs < NS; cs++) {
                     const int df = srt[cs] - relMine;
                     const double trI = (fabs((double)df) - 1.0) * IIf;
-                    tA[cs] = (cs < l16) ? trI + lE : (cs == l16 ? l1mE : FNEG_INF);   // on-diagonal source cs <= own (:380-384)
-                    tB[cs] = (cs > l16) ? trI : FNEG_INF;                              // inserted source cs > own (:404-411)
-                    dL[cs] = (cs > l16) ? df : 0x7fffffff;                             // its condition relPos[cs]-r >= relPos[ns]
+                    tA[cs] = (cs < lv) ? trI + lE : (cs == lv ? l1mE : FNEG_INF);   // on-diagonal source cs <= own (:380-384)
+                    tB[cs] = (cs > lv) ? trI : FNEG_INF;                              // inserted source cs > own (:404-411)
+                    dL[cs] = (cs > lv) ? df : 0x7fffffff;                             // its condition relPos[cs]-r >= relPos[ns]
                     asm volatile("" : "+v"(tA[cs]), "+v"(tB[cs]), "+v"(dL[cs]));           // keep them as plain register constants
                 }
                 const int rows = gmax4(bMid);
@@ -342,8 +356,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int cs = 0; cs < NS; cs++) {
                     const int df = srt[cs] - relMine;
                     const double trI = (fabs((double)df) - 1.0) * IIf;
-                    tD[cs] = (cs < l16) ? trI : FNEG_INF;                  // into the inserted state of a higher diagonal (:453-461)
-                    tA[cs] = (cs > l16) ? trI + lE : FNEG_INF;             // on-diagonal source cs > own (:427-431); own: below
+                    tD[cs] = (cs < lv) ? trI : FNEG_INF;                  // into the inserted state of a higher diagonal (:453-461)
+                    tA[cs] = (cs > lv) ? trI + lE : FNEG_INF;             // on-diagonal source cs > own (:427-431); own: below
                     dR[cs] = df;                                           // condition relPos[cs] > relPos[ns]-r
                     asm volatile("" : "+v"(tD[cs]), "+v"(tA[cs]), "+v"(dR[cs]));
                 }
@@ -542,17 +556,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (l16 == 0 && good) {
                 P.out.ll[pair] = ll;
                 P.out.status[pair] = DD_PAIR_OK;             // computeLikelihoodsFaster has no ll checks
-                if (P.out.llOn) P.out.llOn[pair] = 0.0;
-                if (P.out.llOff) P.out.llOff[pair] = 0.0;
-                if (P.out.mLogBQ) P.out.mLogBQ[pair] = 0.0;
-                if (P.out.offHap) P.out.offHap[pair] = 0;       // always false (:491)
-                if (P.out.offHapHMQ) P.out.offHapHMQ[pair] = 0; // always false (:529)
-                if (P.out.numIndels) P.out.numIndels[pair] = 0;
-                if (P.out.numMismatch) P.out.numMismatch[pair] = 0;
-                if (P.out.nBQT) P.out.nBQT[pair] = 0;
-                if (P.out.nmmBQT) P.out.nmmBQT[pair] = 0;
-                if (P.out.nMMLeft) P.out.nMMLeft[pair] = 0;
-                if (P.out.nMMRight) P.out.nMMRight[pair] = 0;
                 if (P.out.firstBase) P.out.firstBase[pair] = (int16_t)firstB;
                 if (P.out.lastBase) P.out.lastBase[pair] = (int16_t)lastB;
             }
