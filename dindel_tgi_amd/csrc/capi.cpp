@@ -527,7 +527,6 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
     int64_t grid = (int64_t)(hap_end - hap_begin) * split;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (grid > 0) {
-        if (grid > 65536) grid = 65536;            // workgroups stride over the items
         g_last_launch[0] = groups; g_last_launch[1] = 0; g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
         g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes; g_last_launch[7] = 0;
         HIP_TRY(ddk::launch_faster(A, (unsigned)grid, waves, lds, st));

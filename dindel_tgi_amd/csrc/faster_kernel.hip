@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     for (int i = tid; i < P.n_qual; i += blockDim.x) qt[i] = make_double2(T[T_QUAL + 4 * i], T[T_QUAL + 4 * i + 1]);
 
-    for (int item = P.item_begin + blockIdx.x; item < P.n_items; item += gridDim.x) {
+    for (int item = P.item_begin + xcd_contiguous_block_id(P.n_items - P.item_begin); item < P.n_items; item += gridDim.x) {
         const int g = item / P.n_split, split = item - g * P.n_split;
         const int w = P.hap_window[g], h0 = P.win_hap_off[w];
         const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1], R = r1 - r0;

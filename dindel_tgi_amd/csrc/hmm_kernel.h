@@ -65,6 +65,18 @@ struct KernelArgs {
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
 };
 
+/* Workgroups are dealt round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own L2.  The haplotypes of a
+ * window re-read the same reads, so consecutive items should land on ONE XCD: XCD x takes the x-th contiguous eighth of
+ * the grid's index range.  Bijection on [0, gridDim.x).  Only for one-shot grids (one item per workgroup): a persistent grid
+ * whose last round is partial would leave that round's items on the first XCDs alone. */
+__device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
+{
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    if (G < n_items_in_launch) return b;
+    const int x = b & 7, q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */

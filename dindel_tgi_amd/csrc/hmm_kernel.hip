@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     STAMP_INIT;
 
     // ======================= loop over this workgroup's (haplotype, read-slice) items =======================
-    for (int item = P.item_begin + blockIdx.x; item < P.n_items; item += gridDim.x) {
+    for (int item = P.item_begin + xcd_contiguous_block_id(P.n_items - P.item_begin); item < P.n_items; item += gridDim.x) {
     __syncthreads();                               // every wave is done with the previous haplotype's LDS tables
     const int gi = item / P.n_split;
     const int split = item - gi * P.n_split;

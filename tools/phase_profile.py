@@ -20,7 +20,7 @@ so = os.path.join(out_dir, "libdindel_hmm_stamps.so")
 src = os.path.join(ROOT, "dindel_tgi_amd", "csrc")
 only = os.environ.get("DD_ONLY", "-DDD_ONLY_K=2 -DDD_ONLY_D=6")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-DDD_STAMPS",
-       *only.split(), "-shared", "-o", so, os.path.join(src, "hmm_kernel.hip"), os.path.join(src, "genotype_kernel.hip"), os.path.join(src, "capi.cpp")]
+       *only.split(), "-shared", "-o", so, os.path.join(src, "hmm_kernel.hip"), os.path.join(src, "genotype_kernel.hip"), os.path.join(src, "faster_kernel.hip"), os.path.join(src, "capi.cpp")]
 subprocess.check_call(cmd)
 capi.LIB_PATH = so
 lib = capi.load()
