@@ -99,7 +99,7 @@ class dd_device_result(C.Structure):
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
            "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
-           "dd_pair_sums", "dd_last_error", "dd_abi_version", "dd_device_count"]
+           "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
 _lib = None
 
@@ -139,6 +139,8 @@ def load():
     lib.dd_pair_sum_offsets.argtypes = [C.POINTER(dd_batch), c_i64p]
     lib.dd_pair_sums_device.argtypes = [C.POINTER(dd_device_batch), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_pair_sums.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p, C.c_int]
+    lib.dd_map_pairs_device.argtypes = [C.POINTER(dd_device_batch)] + [C.c_void_p] * 9
+    lib.dd_map_pairs.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p, C.POINTER(C.c_uint8), c_i32p, c_f64p, c_f64p, c_i32p, c_f64p, C.c_int]
     lib.dd_last_launch.argtypes = [C.POINTER(C.c_int32 * 8)]
     lib.dd_last_launch.restype = None
     lib.dd_kernel_name.restype = C.c_char_p

@@ -649,6 +649,73 @@ int dd_pair_sums_device(const dd_device_batch *b, const int64_t *win_hh_off_dev,
     return DD_SUCCESS;
 }
 
+int dd_map_pairs_device(const dd_device_batch *b, const int64_t *win_hh_off_dev, const double *pair_sum_dev, const double *prior_dev,
+                        const uint8_t *filtered_dev, const int32_t *ncand_dev, double *posterior_dev, int32_t *pairs_dev,
+                        double *vals_dev, void *stream)
+{
+    if (!b || !win_hh_off_dev || !pair_sum_dev || !prior_dev || !filtered_dev || !ncand_dev || !pairs_dev || !vals_dev)
+        return fail(DD_ERR_INVALID, "null argument");
+    ddk::MapPairArgs A;
+    A.n_windows = b->n_windows; A.win_hap_off = b->win_hap_off; A.win_hh_off = win_hh_off_dev;
+    A.pair_sum = pair_sum_dev; A.prior = prior_dev; A.filtered = filtered_dev; A.ncand = ncand_dev;
+    A.posterior = posterior_dev; A.pairs = pairs_dev; A.vals = vals_dev;
+    HIP_TRY(ddk::launch_map_pairs(A, static_cast<hipStream_t>(stream)));
+    return DD_SUCCESS;
+}
+
+int dd_map_pairs(const dd_batch *b, const double *ll_host, const double *prior_host, const uint8_t *filtered_host,
+                 const int32_t *ncand_host, double *pair_sum_out, double *posterior_out, int32_t *pairs_out, double *vals_out, int device)
+{
+    dd_sizes sz;
+    int rc = dd_batch_sizes(b, &sz);
+    if (rc) return rc;
+    if (!ll_host || !prior_host || !filtered_host || !ncand_host || !pairs_out || !vals_out) return fail(DD_ERR_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DD_ERR_NO_DEVICE, "no HIP device: the genotype reduction has no CPU fallback in this library");
+    if (device < 0 || device >= ndev) return fail(DD_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    const int W = b->n_windows;
+    if (W <= 0) return DD_SUCCESS;
+    std::vector<int64_t> pair_off(W + 1), hh_off(W + 1);
+    dd_batch_offsets(b, pair_off.data(), nullptr, nullptr);
+    dd_pair_sum_offsets(b, hh_off.data());
+    const size_t ns = (size_t)hh_off[W];
+    DeviceCtx &ctx = g_ctx.c;
+    if ((rc = ctx.reserve(device, (size_t)(2 * (W + 1) * 4 + 2 * (W + 1) * 8 + ((size_t)sz.n_pairs + 3 * ns) * 8 + (size_t)sz.n_haps * 5 + (size_t)W * 40 + 32 * 256), 0))) return rc;
+    DevBuf dev(ctx);
+    dd_device_batch db;
+    memset(&db, 0, sizeof(db));
+    db.n_windows = W;
+    if ((rc = dev.upload(&db.win_hap_off, b->win_hap_off, (size_t)W + 1))) return rc;
+    if ((rc = dev.upload(&db.win_read_off, b->win_read_off, (size_t)W + 1))) return rc;
+    if ((rc = dev.upload(&db.win_pair_off, (const int64_t *)pair_off.data(), pair_off.size()))) return rc;
+    const int64_t *hh_dev = nullptr;
+    const double *ll_dev = nullptr, *prior_dev = nullptr;
+    const uint8_t *filt_dev = nullptr;
+    const int32_t *nc_dev = nullptr;
+    double *sum_dev = nullptr, *post_dev = nullptr, *vals_dev = nullptr;
+    int32_t *pairs_dev = nullptr;
+    if ((rc = dev.upload(&hh_dev, (const int64_t *)hh_off.data(), hh_off.size()))) return rc;
+    if ((rc = dev.upload(&ll_dev, ll_host, (size_t)sz.n_pairs))) return rc;
+    if ((rc = dev.upload(&prior_dev, prior_host, ns))) return rc;
+    if ((rc = dev.upload(&filt_dev, filtered_host, (size_t)sz.n_haps))) return rc;
+    if ((rc = dev.upload(&nc_dev, ncand_host, (size_t)sz.n_haps))) return rc;
+    if ((rc = dev.alloc(&sum_dev, ns))) return rc;
+    if ((rc = dev.alloc(&post_dev, ns))) return rc;
+    if ((rc = dev.alloc(&vals_dev, (size_t)3 * W))) return rc;
+    if ((rc = dev.alloc(&pairs_dev, (size_t)4 * W))) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if ((rc = dd_pair_sums_device(&db, hh_dev, hh_off[W], ll_dev, sum_dev, nullptr))) return rc;
+    if ((rc = dd_map_pairs_device(&db, hh_dev, sum_dev, prior_dev, filt_dev, nc_dev, post_dev, pairs_dev, vals_dev, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (pair_sum_out) HIP_TRY(hipMemcpy(pair_sum_out, sum_dev, ns * sizeof(double), hipMemcpyDeviceToHost));
+    if (posterior_out) HIP_TRY(hipMemcpy(posterior_out, post_dev, ns * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pairs_out, pairs_dev, (size_t)4 * W * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vals_out, vals_dev, (size_t)3 * W * sizeof(double), hipMemcpyDeviceToHost));
+    return DD_SUCCESS;
+}
+
 int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int device)
 {
     dd_sizes sz;

@@ -58,6 +58,60 @@ __global__ void __launch_bounds__(256) dd_pair_sum_kernel(PairSumArgs P)
     if (lane == 0) P.out[slot] = sum;
 }
 
+// MAP haplotype pairs of DetInDel::diploidGLF (reference DInDel.cpp:3073-3118): per window
+//     pairs_posterior[h1,h2] = S[h1,h2] + prior[h1,h2]            for unfiltered h1 <= h2                    (:3091)
+//     (max_ll_indel, pair) = first strict maximum over pairs with a candidate indel on either haplotype      (:3103)
+//     (max_ll_noindel, pair) = the same over pairs with none                                                 (:3108)
+//     qual = -10 (ll_ref - addLogs(max_ll_indel, ll_ref)) / ln 10,  ll_ref = max_ll_noindel                  (:3116-3118)
+// One wavefront per window; the reference scans (h1,h2) in row-major order with `>`, i.e. takes the FIRST maximum:
+// lanes keep (value, slot) of their own ascending slots and the reduction prefers the smaller slot on equal values.
+__global__ void __launch_bounds__(256) dd_map_pair_kernel(MapPairArgs P)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= P.n_windows) return;
+    const int h0 = P.win_hap_off[w], H = P.win_hap_off[w + 1] - h0;
+    const int64_t base = P.win_hh_off[w];
+    double bi = -__builtin_huge_val(), bn = -__builtin_huge_val();
+    int ii = 0x7fffffff, in_ = 0x7fffffff;
+    for (int idx = lane; idx < H * H; idx += 64) {
+        const int h1 = idx / H, h2 = idx - h1 * H;
+        double pp = 0.0;
+        if (h2 >= h1 && !P.filtered[h0 + h1] && !P.filtered[h0 + h2]) {
+            pp = P.pair_sum[base + idx] + P.prior[base + idx];
+            const bool cand = P.ncand[h0 + h1] > 0 || P.ncand[h0 + h2] > 0;
+            if (cand && pp > bi) { bi = pp; ii = idx; }
+            if (!cand && pp > bn) { bn = pp; in_ = idx; }
+        }
+        if (P.posterior) P.posterior[base + idx] = pp;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double obi = __shfl_xor(bi, off), obn = __shfl_xor(bn, off);
+        const int oii = __shfl_xor(ii, off), oin = __shfl_xor(in_, off);
+        if (obi > bi || (obi == bi && oii < ii)) { bi = obi; ii = oii; }
+        if (obn > bn || (obn == bn && oin < in_)) { bn = obn; in_ = oin; }
+    }
+    if (lane == 0) {
+        const bool hi = ii != 0x7fffffff && bi > -__builtin_huge_val(), hn = in_ != 0x7fffffff && bn > -__builtin_huge_val();
+        P.pairs[4 * w + 0] = hi ? ii / H : -1;
+        P.pairs[4 * w + 1] = hi ? ii % H : -1;
+        P.pairs[4 * w + 2] = hn ? in_ / H : -1;
+        P.pairs[4 * w + 3] = hn ? in_ % H : -1;
+        const double mi = hi ? bi : -__builtin_huge_val(), mn = hn ? bn : -__builtin_huge_val();
+        P.vals[3 * w + 0] = mi;
+        P.vals[3 * w + 1] = mn;
+        P.vals[3 * w + 2] = -10.0 * (mn - add_logs(mi, mn)) / log(10.0);
+    }
+}
+
+hipError_t launch_map_pairs(const MapPairArgs &A, hipStream_t st)
+{
+    if (A.n_windows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dd_map_pair_kernel, dim3((unsigned)((A.n_windows + 3) / 4)), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_sums(const PairSumArgs &A, hipStream_t st)
 {
     if (A.n_slots <= 0) return hipSuccess;

@@ -92,5 +92,19 @@ struct PairSumArgs {
 };
 hipError_t launch_pair_sums(const PairSumArgs &A, hipStream_t st);
 
+/* N1: MAP haplotype pairs + qual per window (genotype_kernel.hip) */
+struct MapPairArgs {
+    int32_t n_windows;
+    const int32_t *win_hap_off;
+    const int64_t *win_hh_off;
+    const double *pair_sum, *prior;  /* [n_slots] */
+    const uint8_t *filtered;         /* [n_haps] */
+    const int32_t *ncand;            /* [n_haps] hap_num_candidate_indels */
+    double *posterior;               /* [n_slots] or NULL */
+    int32_t *pairs;                  /* [4*n_windows] */
+    double *vals;                    /* [3*n_windows] */
+};
+hipError_t launch_map_pairs(const MapPairArgs &A, hipStream_t st);
+
 } // namespace ddk
 #endif

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 4
+#define DD_ABI_VERSION 5
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -221,6 +221,22 @@ int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off);
 int dd_pair_sums_device(const dd_device_batch *b, const int64_t *win_hh_off_dev, int64_t n_slots,
                         const double *ll_dev, double *out_dev, void *stream);
 int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int device);
+
+/* MAP haplotype pairs of the same function (reference DInDel.cpp:3073-3118), per window, on the device:
+ *   posterior[h1*H+h2] = S[h1,h2] + prior[h1,h2] for h1<=h2 with filtered[h1]==filtered[h2]==0 (0 elsewhere)     (:3091)
+ *   pairs[4w+0..1] = first strict maximum among pairs with ncand[h1]>0 || ncand[h2]>0  (max_indel_pair, -1 if none) (:3103)
+ *   pairs[4w+2..3] = the same among pairs with no candidate indel (max_noindel_pair)                                (:3108)
+ *   vals[3w+0..2]  = max_ll_indel, max_ll_noindel (= ll_ref), qual = -10 (ll_ref - addLogs(max_ll_indel, ll_ref)) / ln 10 (:3116-3118)
+ * prior = DetInDel::getHaplotypePrior per pair (:3064-3068, host data), filtered[n_haps] from filterHaplotypes (:2941),
+ * ncand[n_haps] = hap_num_candidate_indels (:2984-2993).  The caller raises the reference's
+ * `throw string("Could not find indel allele")` (:3121) when pairs[4w] == -1.
+ * dd_map_pairs: host pointers; runs the read sums (from `ll`) and this step in one go; pair_sum_out / posterior_out may be NULL. */
+int dd_map_pairs_device(const dd_device_batch *b, const int64_t *win_hh_off_dev, const double *pair_sum_dev,
+                        const double *prior_dev, const uint8_t *filtered_dev, const int32_t *ncand_dev,
+                        double *posterior_dev, int32_t *pairs_dev, double *vals_dev, void *stream);
+int dd_map_pairs(const dd_batch *b, const double *ll_host, const double *prior_host, const uint8_t *filtered_host,
+                 const int32_t *ncand_host, double *pair_sum_out, double *posterior_out, int32_t *pairs_out,
+                 double *vals_out, int device);
 
 /* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
 const char *dd_kernel_name(void);

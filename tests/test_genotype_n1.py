@@ -112,6 +112,58 @@ def test_device_pair_sums(lib, cfg):
     assert (dev[want == 0] == 0).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(n=40, H=8, R=60), dict(n=30, H=3, R=33, vary_read_len=True, mixed_quals=True),
+                                 dict(n=6, H=1, R=3), dict(n=9, H=13, R=5)])
+def test_device_map_pairs(lib, cfg):
+    """dd_map_pairs: read sums + MAP indel / no-indel pairs + qual per window on the device, against the Python
+    restatement of DInDel.cpp:3073-3118 fed with the oracle's read sums.  Pair indices exact (the test priors take few
+    distinct values, so equal posteriors between pairs DO occur through equal read sums of identical haplotypes);
+    values within 1e-12 (device exp/log vs glibc)."""
+    from tests.test_gpu_parity import run_host_api
+    cfg = dict(cfg)
+    n = cfg.pop("n")
+    pb = synth.generate(n, L=60, hap_len=70, seed=31, **cfg)
+    p = capi.params_cli_defaults()
+    got = run_host_api(lib, p, pb)
+    b = pb.ctypes_batch()
+    hh = np.zeros(n + 1, np.int64)
+    lib.dd_pair_sum_offsets(C.byref(b), hh.ctypes.data_as(capi.c_i64p))
+    ns = int(hh[-1])
+    rng = np.random.default_rng(7)
+    prior = np.log(rng.choice([1e-4, 1e-3, 1.0], ns))
+    nhap = pb.n_haps
+    filtered = (rng.random(nhap) < 0.15).astype(np.uint8)
+    ncand = rng.integers(0, 2, nhap).astype(np.int32)
+    sums = np.zeros(ns); post = np.zeros(ns); pairs = np.zeros(4 * n, np.int32); vals = np.zeros(3 * n)
+    rc = lib.dd_map_pairs(C.byref(b), got["ll"].ctypes.data_as(capi.c_f64p), prior.ctypes.data_as(capi.c_f64p),
+                          filtered.ctypes.data_as(C.POINTER(C.c_uint8)), ncand.ctypes.data_as(capi.c_i32p),
+                          sums.ctypes.data_as(capi.c_f64p), post.ctypes.data_as(capi.c_f64p), pairs.ctypes.data_as(capi.c_i32p),
+                          vals.ctypes.data_as(capi.c_f64p), 0)
+    assert rc == 0, capi.last_error()
+    want_sums = np.zeros(ns)
+    _oracle.load().ddo_pair_sums(C.byref(b), got["ll"].ctypes.data_as(capi.c_f64p), want_sums.ctypes.data_as(capi.c_f64p))
+    np.testing.assert_allclose(sums, want_sums, rtol=1e-12, atol=0)
+    hoff = pb.a["win_hap_off"]
+    n_none = 0
+    for w in range(n):
+        h0, h1 = int(hoff[w]), int(hoff[w + 1])
+        nh = h1 - h0
+        sl = slice(int(hh[w]), int(hh[w + 1]))
+        # index decisions are made on the device's own sums (they are what its comparisons see)
+        wpost, pi, pn, mi, mn, qual = py_pair_posteriors(nh, sums[sl], prior[sl], filtered[h0:h1], ncand[h0:h1])
+        assert np.array_equal(post[sl], wpost)
+        assert pairs[4 * w:4 * w + 4].tolist() == pi + pn, w
+        assert vals[3 * w] == mi and vals[3 * w + 1] == mn
+        if pi == [-1, -1]:
+            n_none += 1
+        if math.isfinite(qual):
+            assert vals[3 * w + 2] == pytest.approx(qual, rel=1e-12, abs=1e-12)
+        else:
+            assert vals[3 * w + 2] == qual or (math.isnan(qual) and math.isnan(vals[3 * w + 2]))
+    assert n_none < n
+
+
 def py_filter_flags(pb, params, res):
     """filterHaplotypes' per-(haplotype variant, read) coverage test restated in Python straight from the reference
     loop (DInDel.cpp:1951-2054), set-based like the reference; b < L (the reference's b <= L is out of bounds)."""
