@@ -232,3 +232,40 @@ def test_hbm_scratch_tile_reuse_many_reads_per_wave(lib):
         reads += reads_from(hap, 12, L, junk=0.05) + reads_from(haps[1], 10, L, junk=0.0)
     pb, got = check(lib, [Window(1000, haps, reads), Window(5000, haps[::-1], reads[::-1])], p)
     assert capi.last_launch()["D"] >= 100
+
+
+def test_indel_length_ladder_and_end_insertions(lib):
+    """SURVEY §8(c) fixture plan: reads carrying a deletion of every length 1..maxLengthDel+1 (the last one is not
+    reachable by a single jump), insertions of 1..4 bases at the first / last read base and right at the haplotype
+    ends, for maxLengthDel 5 and 10; the number of indels the path reports is cross-checked, not only parity."""
+    for p in (capi.params_cli_defaults(), capi.params_struct_defaults()):
+        D = p.maxLengthDel
+        hap = rnd(140)
+        reads = []
+        for ln in range(1, D + 2):
+            s = hap[20:60] + hap[60 + ln:100 + ln]                       # deletion of ln bases after hap base 59
+            reads.append(ReadRec(s, [0.999] * len(s), 0.9999, 1020))
+        for ln in range(1, 5):
+            ins = rnd(ln)
+            for s, pos in ((ins + hap[30:90], 1030 - ln), (hap[30:90] + ins, 1030), (ins + hap[0:50], 1000 - ln),
+                           (hap[90:140] + ins, 1090), (hap[30:60] + ins + hap[60:90], 1030)):
+                reads.append(ReadRec(s, [0.999] * len(s), 0.9999, pos))
+        pb, got = check(lib, [Window(1000, [hap], reads)], p)
+        nind = got["numIndels"][:pb.n_pairs]
+        assert (nind[:D] == 1).all()                                       # one deletion each, lengths 1..maxLengthDel
+        assert got["offHap"][D] == 1 or nind[D] != 1                      # maxLengthDel+1: no single-jump explanation
+
+
+def test_mapping_quality_ladder_and_cap(lib):
+    """Mapping qualities from Phred 0 to 120 (mapQualThreshold caps the prior at Phred 100, ObservationModelFB.cpp:276)
+    on reads that match, mismatch and do not belong: llOn / llOff / offHap follow the prior bit for bit."""
+    hap = rnd(120)
+    good, bad = hap[10:110], rnd(100)
+    reads = []
+    for ph in list(range(0, 64, 3)) + [80, 99, 100, 101, 120, 150]:
+        mq = min(1.0 - 10.0 ** (-ph / 10.0), 1.0 - 1e-16) if ph else 0.0
+        reads.append(ReadRec(good, [0.999] * 100, mq, 1010))
+        reads.append(ReadRec(bad, [0.999] * 100, mq, 1010))
+        reads.append(ReadRec(mutate(good, 0.15), [0.99] * 100, mq, 1010))
+    pb, got = check(lib, [Window(1000, [hap, hap[:60] + hap[63:]], reads)])
+    assert got["offHap"][:pb.n_pairs].any() and not got["offHap"][:pb.n_pairs].all()
