@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Long randomised GPU-vs-oracle parity campaign (both models), beyond what the test-suite budget allows.
+  python tools/fuzz_campaign.py [--seconds 300] [--seed0 0]
+Every round draws a shape class, parameters and adversarial windows (tests/test_gpu_fuzz.make_windows plus
+synth.generate mixes), runs the C ABI and the oracle (16 threads) and requires bit-equality.  Prints one line per
+round; exits non-zero at the first mismatch after dumping the seed."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from dindel_tgi_amd import capi, synth
+from dindel_tgi_amd.batch import pack
+from tests import _oracle
+from tests.test_gpu_fuzz import make_windows
+from tests.test_gpu_parity import assert_same, run_host_api
+from tests.test_gpu_faster import assert_same_faster, run_faster
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=300)
+ap.add_argument("--seed0", type=int, default=0)
+args = ap.parse_args()
+lib = capi.load()
+t_end = time.time() + args.seconds
+rnd = 0
+pairs = 0
+while time.time() < t_end:
+    seed = args.seed0 + rnd
+    rng = np.random.default_rng(50000 + seed)
+    kind = int(rng.integers(0, 3))
+    p = capi.params_cli_defaults() if rng.random() < 0.5 else capi.params_struct_defaults()
+    p.maxLengthDel = int(rng.integers(0, 12))
+    p.padCover = int(rng.integers(0, 6))
+    p.maxMismatch = int(rng.integers(0, 4))
+    p.pError = float(rng.choice([5e-4, 1e-4, 1e-2, 0.2]))
+    p.pMut = float(rng.choice([1e-5, 1e-4, 1e-2]))
+    p.mapQualThreshold = float(rng.choice([100.0, 40.0, 10.0]))
+    p.capMapQualFast = float(rng.choice([45.0, 40.0, 5.0, 300.0]))
+    if rng.random() < 0.15:
+        p.bMid = int(rng.integers(0, 30))
+    if kind == 0:
+        max_hap = int(rng.choice([40, 62, 126, 190, 254, 400, 755]))   # make_windows adds up to 7 inserted bases
+        ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1)
+        pb = pack(ws)
+    elif kind == 1:
+        pb = synth.generate(int(rng.integers(1, 8)), H=int(rng.integers(1, 17)), R=int(rng.integers(1, 300)),
+                            L=int(rng.integers(8, 260)), hap_len=int(rng.integers(24, 400)), seed=seed,
+                            max_indel=int(rng.integers(1, 9)), sub_rate=float(rng.choice([1e-3, 0.02, 0.2])),
+                            vary_read_len=bool(rng.random() < 0.5), mixed_quals=bool(rng.random() < 0.7))
+    else:
+        pb = synth.generate(int(rng.integers(20, 200)), H=int(rng.integers(2, 9)), R=int(rng.integers(10, 60)),
+                            L=int(rng.choice([36, 76, 100])), hap_len=int(rng.integers(40, 170)), seed=seed,
+                            mixed_quals=True, sub_rate=float(rng.choice([1e-3, 0.01])))
+    try:
+        assert_same(run_host_api(lib, p, pb), _oracle.batch(p, pb, nthreads=16), pb)
+        assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=16, faster=True), pb)
+    except AssertionError as e:
+        print("MISMATCH at seed", seed, "kind", kind, "params", {f: getattr(p, f) for f, _ in p._fields_}, flush=True)
+        print(str(e)[:2000], flush=True)
+        sys.exit(1)
+    pairs += pb.n_pairs
+    print("round %d seed %d kind %d pairs %d (total %d) max_hap %d max_read %d mld %d ok" %
+          (rnd, seed, kind, pb.n_pairs, pairs, pb.max_hap_len, pb.max_read_len, p.maxLengthDel), flush=True)
+    rnd += 1
+print("campaign ok: %d rounds, %d pairs per model" % (rnd, pairs))
