@@ -213,3 +213,32 @@ def test_faster_launch_is_graph_capturable(lib):
     got = dev.results()
     for k in want:
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_concurrent_host_threads_both_models(lib):
+    """The host-pointer entry points keep their device arena, streams and the model switch per host thread: three
+    threads hammer both models on different batches at once; every result equals the single-threaded one."""
+    import threading
+    from tests.test_gpu_parity import run_host_api
+    p = capi.params_cli_defaults()
+    pbs = [synth.generate(6 + i, H=4 + i, R=40, seed=170 + i, mixed_quals=True) for i in range(3)]
+    want = [(run_host_api(lib, p, pb), run_faster(lib, p, pb)) for pb in pbs]
+    errors = []
+
+    def work(i):
+        try:
+            for rep in range(6):
+                a = run_faster(lib, p, pbs[i]) if (rep + i) % 2 else run_host_api(lib, p, pbs[i])
+                w = want[i][1] if (rep + i) % 2 else want[i][0]
+                for k in ("ll", "status", "firstBase", "lastBase", "offHap"):
+                    assert np.array_equal(a[k][:pbs[i].n_pairs], w[k][:pbs[i].n_pairs]), (i, rep, k)
+                assert np.array_equal(a["hpos"][:pbs[i].hpos_len], w["hpos"][:pbs[i].hpos_len]), (i, rep)
+        except Exception as e:          # noqa: BLE001 - surfaced below
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
