@@ -10,5 +10,5 @@ g++ -O1 -g -fPIC -std=c++11 -fsanitize=address,undefined -fno-omit-frame-pointer
     -Wl,-rpath,"$ROOT/dindel_tgi_amd/csrc"
 cd "$ROOT"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 DD_ORACLE_LIB=/tmp/libdd_oracle_asan.so \
-    DD_HOST_LIB=/tmp/libdindel_host_asan.so python -m pytest tests/test_oracle_kat.py tests/test_host_adapter_cpu.py \
+    DD_HOST_LIB=/tmp/libdindel_host_asan.so python -m pytest tests/test_oracle_kat.py tests/test_oracle_fast_cpu.py tests/test_host_adapter_cpu.py \
     tests/test_genotype_n1.py -q -m "not gpu" -p no:cacheprovider
