@@ -1,5 +1,8 @@
 // compute_likelihoods.cpp — see compute_likelihoods.hpp.
 #include "compute_likelihoods.hpp"
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -178,6 +181,7 @@ void LikelihoodEngine::computeLikelihoods(const std::vector<Haplotype> &haps, co
 
 void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
 {
+    const std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
     const int W = int(jobs.size());
     // ---- pack (CSR) ----
     std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, hap_var_flank, read_seq_off(1, 0);
@@ -211,11 +215,16 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
             if (R.qual.size() != R.size()) throw std::string("Read: qual and seq differ in length");
             read_seq += R.seq.seq;
             read_seq_off.push_back(int32_t(read_seq.size()));
+            double lastq = -1.0;
+            int lastidx = 0;
             for (size_t b = 0; b < R.qual.size(); b++) {
-                std::map<double, int>::iterator it = qmap.find(R.qual[b]);
-                if (it == qmap.end()) { it = qmap.insert(std::make_pair(R.qual[b], int(qtab.size()))).first; qtab.push_back(R.qual[b]); }
-                if (it->second > 255) throw std::string("more than 256 distinct base qualities in one batch");
-                read_qidx.push_back(uint8_t(it->second));
+                if (R.qual[b] != lastq) {                 // runs of equal qualities skip the map
+                    std::map<double, int>::iterator it = qmap.find(R.qual[b]);
+                    if (it == qmap.end()) { it = qmap.insert(std::make_pair(R.qual[b], int(qtab.size()))).first; qtab.push_back(R.qual[b]); }
+                    if (it->second > 255) throw std::string("more than 256 distinct base qualities in one batch");
+                    lastq = R.qual[b]; lastidx = it->second;
+                }
+                read_qidx.push_back(uint8_t(lastidx));
             }
             std::map<double, int>::iterator it = mqmap.find(R.mapQual);
             if (it == mqmap.end()) { it = mqmap.insert(std::make_pair(R.mapQual, int(mqtab.size()))).first; mqtab.push_back(R.mapQual); }
@@ -245,22 +254,30 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     std::vector<double> ll(sz.n_pairs), llOn(sz.n_pairs), llOff(sz.n_pairs), mLogBQ(sz.n_pairs);
     std::vector<uint8_t> offHap(sz.n_pairs), offHapHMQ(sz.n_pairs), onHapV(sz.n_reads ? sz.n_reads : 1);
     std::vector<int16_t> hpos(sz.hpos_len ? sz.hpos_len : 1);
+    std::vector<int16_t> numIndels(sz.n_pairs), numMismatch(sz.n_pairs), nBQT(sz.n_pairs), nmmBQT(sz.n_pairs), nMMLeft(sz.n_pairs),
+        nMMRight(sz.n_pairs), firstBase(sz.n_pairs), lastBase(sz.n_pairs);
     std::vector<int32_t> status(sz.n_pairs);
-    std::vector<uint8_t> fcov(sz.var_cov_len ? sz.var_cov_len : 1);
+    std::vector<uint8_t> fcov(sz.var_cov_len ? sz.var_cov_len : 1), vcov(sz.var_cov_len ? sz.var_cov_len : 1);
     dd_result Rz;
     memset(&Rz, 0, sizeof(Rz));
     Rz.ll = ll.data(); Rz.llOn = llOn.data(); Rz.llOff = llOff.data(); Rz.mLogBQ = mLogBQ.data();
     Rz.offHap = offHap.data(); Rz.offHapHMQ = offHapHMQ.data(); Rz.hpos = hpos.data(); Rz.status = status.data();
+    Rz.numIndels = numIndels.data(); Rz.numMismatch = numMismatch.data(); Rz.nBQT = nBQT.data(); Rz.nmmBQT = nmmBQT.data();
+    Rz.nMMLeft = nMMLeft.data(); Rz.nMMRight = nMMRight.data(); Rz.firstBase = firstBase.data(); Rz.lastBase = lastBase.data();
     Rz.onHap = onHapV.data();
-    Rz.var_fcov = fcov.data();
+    Rz.var_fcov = fcov.data(); Rz.var_covered = vcov.data();
     const dd_params P = to_abi(params);
+    const std::chrono::steady_clock::time_point t_packed = std::chrono::steady_clock::now();
     if (sz.n_pairs > 0) {
         const int rc = faster ? dd_compute_likelihoods_faster(&P, &B, &Rz, device_) : dd_compute_likelihoods(&P, &B, &Rz, device_);
         if (rc != DD_SUCCESS) throw std::string(faster ? "dd_compute_likelihoods_faster: " : "dd_compute_likelihoods: ") + dd_last_error();
     }
 
-    // ---- unpack into liks[hidx][r] / onHap, window by window, in order ----
-    for (int w = 0; w < W; w++) {
+    const std::chrono::steady_clock::time_point t_device = std::chrono::steady_clock::now();
+    // ---- unpack into liks[hidx][r] / onHap: windows are independent, so a few host threads share them ----
+    // Per pair the device already delivers every counter of the record; the variant maps and the `align` string need the
+    // per-base walk (rebuildAlignment) only when the read shows an indel or differs from the haplotype segment it sits on.
+    auto unpack_window = [&](int w) {
         WindowJob &J = jobs[w];
         const size_t H = J.haps->size(), Rn = J.reads->size();
         *J.onHap = std::vector<int>(Rn, 0);                                              // DInDel.cpp:1710
@@ -268,27 +285,53 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
         const int r0 = win_read_off[w];
         const int64_t SL = int64_t(read_seq_off[win_read_off[w + 1]]) - read_seq_off[r0];
         for (size_t h = 0; h < H && J.error.empty(); h++) {
+            const Haplotype &Hh = (*J.haps)[h];
+            const int Hs = int(Hh.size());
+            const int g = win_hap_off[w] + int(h);
+            const int nv = hap_var_off[g + 1] - hap_var_off[g];
             for (size_t r = 0; r < Rn; r++) {
                 const int64_t p = pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
                 if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47, Faster.cpp:47
                 if (faster && status[p] != DD_PAIR_OK) { J.error = "HapHash string too short"; break; }   // Haplotype.hpp:341
                 MLAlignment &ml = (*J.liks)[h][r];
+                const Read &Rd = (*J.reads)[r];
+                const int L = int(Rd.size());
                 const int16_t *hp = hpos.data() + hpos_off[w] + int64_t(h) * SL + (read_seq_off[r0 + r] - read_seq_off[r0]);
-                if (faster) rebuildAlignmentFaster((*J.haps)[h], (*J.reads)[r], hp, params, ml);
-                else rebuildAlignment((*J.haps)[h], (*J.reads)[r], hp, params, ml);
+                const int64_t vb = vc_off[w] + int64_t(hap_var_off[g] - hap_var_off[win_hap_off[w]]) * int64_t(Rn) + int64_t(r) * nv;
+                bool plain = false;                       // gap-free, mismatch-free placement: nothing to list
+                if (!faster && numIndels[p] == 0) {
+                    if (firstBase[p] < 0) plain = true;   // no base on the haplotype
+                    else {
+                        int b0 = 0;
+                        while (b0 < L && hp[b0] < 0) b0++;
+                        const int n = lastBase[p] - firstBase[p] + 1;
+                        plain = b0 + n <= L && hp[b0] == firstBase[p] &&
+                                memcmp(Rd.seq.seq.data() + b0, Hh.seq.data() + firstBase[p], size_t(n)) == 0;
+                    }
+                }
+                if (plain) {
+                    ml.align = std::string(size_t(Hs), 'R');
+                    ml.hpos.assign(hp, hp + L);
+                    ml.firstBase = firstBase[p]; ml.lastBase = lastBase[p];
+                    ml.numIndels = 0; ml.numMismatch = numMismatch[p]; ml.nBQT = nBQT[p]; ml.nmmBQT = nmmBQT[p];
+                    ml.nMMLeft = nMMLeft[p]; ml.nMMRight = nMMRight[p];
+                    int i = 0;
+                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
+                        ml.hapIndelCovered[it->first] = vcov[vb + i] != 0;
+                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.snps.begin(); it != Hh.snps.end(); ++it, ++i)
+                        ml.hapSNPCovered[it->first] = vcov[vb + i] != 0;
+                } else if (faster) rebuildAlignmentFaster(Hh, Rd, hp, params, ml);
+                else rebuildAlignment(Hh, Rd, hp, params, ml);
                 ml.ll = ll[p]; ml.llOn = llOn[p]; ml.llOff = llOff[p];
                 ml.offHap = offHap[p] != 0; ml.offHapHMQ = offHapHMQ[p] != 0;
                 if (!faster) ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
                 {   // per haplotype-indel coverage flags of filterHaplotypes, in hap.indels map order (first nvI of the hap's list)
-                    const Haplotype &Hh = (*J.haps)[h];
-                    const int g = win_hap_off[w] + int(h);
-                    const int nv = hap_var_off[g + 1] - hap_var_off[g];
-                    const int64_t vb = vc_off[w] + int64_t(hap_var_off[g] - hap_var_off[win_hap_off[w]]) * int64_t(Rn) + int64_t(r) * nv;
                     int i = 0;
                     for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
                         ml.hapIndelFilterCovered[it->first] = fcov[vb + i] != 0;
                 }
                 if (!ml.offHapHMQ) (*J.onHap)[r] = 1;                                     // DInDel.cpp:1720
+                if (faster) continue;                                                     // computeLikelihoodsFaster has no ll checks
                 if (status[p] == DD_PAIR_LLPOS) {                                         // DInDel.cpp:1722-1731
                     if (throwOnPositive_) { J.error = "Likelihood>0"; break; }
                     std::cout << "hidx: " << h << " r: " << r << std::endl;
@@ -302,7 +345,25 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
                 }
             }
         }
+    };
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr > 16) nthr = 16;
+    if (nthr < 1) nthr = 1;
+    if (hostThreads_ > 0) nthr = unsigned(hostThreads_);
+    if (nthr > unsigned(W)) nthr = unsigned(W > 0 ? W : 1);
+    if (nthr <= 1) {
+        for (int w = 0; w < W; w++) unpack_window(w);
+    } else {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; t++)
+            pool.push_back(std::thread([&]() { for (int w = next++; w < W; w = next++) unpack_window(w); }));
+        for (size_t t = 0; t < pool.size(); t++) pool[t].join();
     }
+    const std::chrono::steady_clock::time_point t_end = std::chrono::steady_clock::now();
+    lastPackSeconds = std::chrono::duration<double>(t_packed - t_start).count();
+    lastDeviceSeconds = std::chrono::duration<double>(t_device - t_packed).count();
+    lastUnpackSeconds = std::chrono::duration<double>(t_end - t_device).count();
 }
 
 } // namespace dindel

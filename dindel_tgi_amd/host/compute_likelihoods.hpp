@@ -31,7 +31,7 @@ struct WindowJob {                      // one call of the reference's computeLi
 class LikelihoodEngine {
 public:
     explicit LikelihoodEngine(const ObservationModelParameters &obsParams, int device = 0)
-        : params(obsParams), device_(device), throwOnPositive_(false) {}
+        : params(obsParams), device_(device), throwOnPositive_(false), hostThreads_(0) {}
 
     ObservationModelParameters params;   // the reference passes this->params.obsParams implicitly (DInDel.cpp:1718)
 
@@ -53,6 +53,11 @@ public:
     void computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs);
 
     void setThrowOnPositiveLikelihood(bool v) { throwOnPositive_ = v; }
+    // host threads rebuilding the MLAlignment records of a batch (0 = min(16, hardware threads))
+    void setHostThreads(int n) { hostThreads_ = n; }
+
+    // wall time of the last batch call's three stages (tools/host_adapter_bench.cpp)
+    double lastPackSeconds = 0.0, lastDeviceSeconds = 0.0, lastUnpackSeconds = 0.0;
 
     // ObservationModelFBMax::reportVariants (ObservationModelFB.cpp:1351-1475) from the device's hpos: fills
     // hpos, indels, snps, align, firstBase/lastBase, counters and the covered maps.  Exposed for tests.
@@ -69,6 +74,7 @@ private:
     void runBatch(std::vector<WindowJob> &jobs, bool faster);
     int device_;
     bool throwOnPositive_;
+    int hostThreads_;
 };
 
 } // namespace dindel

@@ -174,3 +174,34 @@ def test_engine_faster_throws_reference_strings():
     assert _host.compute_window(["ACG"], ["ACGT"], [0.999], [0.9999], [0.0], [0], 0, p, faster=True) == {"throw": "hapSize error."}
     assert _host.compute_window(["ACGTACGTACGT"], ["ACG"], [0.999], [0.9999], [0.0], [0], 0, p, faster=True) == \
         {"throw": "HapHash string too short"}
+
+
+def test_engine_fast_unpack_equals_full_rebuild():
+    """runBatch fills gap-free, mismatch-free pairs from the device's counters without the per-base walk: every record
+    must equal what rebuildAlignment (ObservationModelFBMax::reportVariants restated) derives from the same hpos."""
+    rng = np.random.default_rng(11)
+    ref = "".join(rng.choice(list("ACGT"), 110))
+    haps = [ref, ref[:50] + ref[53:], ref[:60] + "TTG" + ref[60:], ref[:30] + "N" + ref[31:]]
+    reads, quals, mapq, pos = [], [], [], []
+    for i in range(60):
+        src = haps[i % 3]
+        L = int(rng.integers(20, 70))
+        off = int(rng.integers(-10, len(src) - 15))
+        s = [src[j] if 0 <= j < len(src) else str(rng.choice(list("ACGT"))) for j in range(off, off + L)]
+        if i % 5 == 0:
+            s[int(rng.integers(0, L))] = "A"
+        reads.append("".join(s)); quals.append(float(rng.choice([0.999, 0.9, 0.96])))
+        mapq.append(0.9999); pos.append(1000.0 + off)
+    p = capi.params_cli_defaults()
+    res = _host.compute_window(haps, reads, quals, mapq, pos, [0] * len(reads), 1000, p)
+    n_plain = 0
+    for h, hap in enumerate(haps):
+        for r, read in enumerate(reads):
+            ml = res["liks"][h][r]
+            full = _host.rebuild(hap, read, quals[r], ml["hpos"], p)
+            for k in ("numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft", "nMMRight", "firstBase", "lastBase", "align",
+                      "indels", "snps", "hpos"):
+                assert ml[k] == full[k], (h, r, k)
+            assert ml["mLogBQ"] == pytest.approx(full["mLogBQ"], rel=1e-15, abs=0)
+            n_plain += (not ml["indels"] and not ml["snps"])
+    assert 20 < n_plain < len(haps) * len(reads)
