@@ -513,7 +513,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             // DetInDel::filterHaplotypes' per-read test (DInDel.cpp:1951-2054): this model leaves numIndels = 0 and
             // offHapHMQ = false, so every read is selected, and its hpos may skip or repeat haplotype bases: the
-            // covered set is marked base by base (one bit per haplotype base).
+            // covered set is marked base by base (one bit per haplotype base).  Sentinel hpos values (< 0) never cover anything:
+            // an interval reaching below haplotype base 0 is never covered (the reference indexes the sequence with them there).
             if (P.out.var_fcov && P.hap_var_flank && nv > 0) {
                 for (int i = 0; i < nv; i++) {
                     const int32_t *fl = P.hap_var_flank + 3 * (size_t)(P.hap_var_off[g] + i);
@@ -523,10 +524,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         wave_sync();
                         for (int x = l16; x < (hlen + 31) / 32; x += 16) bm[x] = 0;
                         wave_sync();
-                        int nmm = 0, anyIns = 0;
+                        int nmm = 0;
                         for (int b = l16; b < L; b += 16) {
                             const int s2 = st[b];
-                            anyIns |= (s2 >= numS) ? 1 : 0;
                             if (s2 >= 1 && s2 <= hlen) {
                                 const int hb = s2 - 1;
                                 if (hb >= left && hb <= right) {
@@ -544,10 +544,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int off = 8; off >= 1; off >>= 1) {
                             nmm += __shfl_xor(nmm, off, 16);
                             csize += __shfl_xor(csize, off, 16);
-                            anyIns |= __shfl_xor(anyIns, off, 16);
                         }
-                        // hpos of an inserted base is the sentinel -1, which the reference's set also collects (:1989-1991)
-                        if (left == DD_HPOS_INS && anyIns) csize++;
                         cov = (csize >= right - left + 1 && nmm <= P.maxMismatch) ? 1 : 0;
                     }
                     if (l16 == 0 && good) P.out.var_fcov[vb + i] = (uint8_t)cov;

@@ -309,6 +309,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 P.out.status[pair] = DD_PAIR_HAPSIZE;
                 P.out.ll[pair] = 0.0;
             }
+            if (nv > 0) {                                      // coverage flags of a pair the reference throws for: none
+                const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
+                for (int i = lane; i < nv; i += 64) {
+                    if (P.out.var_covered) P.out.var_covered[vb + i] = 0;
+                    if (P.out.var_fcov) P.out.var_fcov[vb + i] = 0;
+                }
+            }
             continue;
         }
 

@@ -139,8 +139,10 @@ typedef struct dd_result {
                              haplotype's indel in DetInDel::filterHaplotypes (DInDel.cpp:1951-2062): read selected
                              (!offHapHMQ && numIndels==0), every haplotype base of [leftFlank-padCover,
                              rightFlank+padCover] aligned to, at most maxMismatch mismatches there.  Needs
-                             dd_batch.hap_var_flank.  (The reference loop also reads hpos[L], one past the end —
-                             undefined behaviour that is not reproduced.) */
+                             dd_batch.hap_var_flank.  Two undefined behaviours of the reference loop are not reproduced:
+                             it reads hpos[L], one past the end; and when leftFlank-padCover < 0 it would count the
+                             negative hpos sentinels as covered positions and index the haplotype sequence with them —
+                             here such an interval is simply never covered.  All pairs of a DD_PAIR_HAPSIZE haplotype get 0. */
 } dd_result;
 
 /* sizes derived from a batch (host-side, O(n_windows + n_haps)) */

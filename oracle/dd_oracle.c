@@ -508,9 +508,11 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
                             int csize = 0, nmm = 0, bb, x;
                             for (bb = 0; bb < L; bb++) {
                                 int hb = hp[bb];
-                                if (hb >= left && hb <= right) {
+                                /* hb < 0 are the INS/LO/RO sentinels: with left < 0 the reference would put them in its set and
+                                 * index haps[h].seq with them (undefined behaviour); here a sentinel never covers anything, so an
+                                 * interval reaching below 0 is never covered */
+                                if (hb >= 0 && hb >= left && hb <= right) {
                                     if (!cset[hb - left]) { cset[hb - left] = 1; csize++; }
-                                    if (hb < 0) continue;   /* sentinel in range (left < 0): the reference reads seq[-1..] here, undefined */
                                     if (kind == 1) { if (hs[hb] != 'N' && hs[hb] != B->read_seq[so + bb]) nmm++; }
                                     else { if (hs[hb] != B->read_seq[so + bb]) nmm++; }
                                 }

@@ -142,8 +142,16 @@ def test_quality_extremes_and_full_tables(lib):
 def test_hapsize_error_status_in_mixed_batch(lib):
     p = capi.params_cli_defaults()                                  # maxLengthDel = 5
     hap = rnd(80)
-    ws = [Window(1000, [hap, "ACGT"], reads_from(hap, 5, 30)),      # second haplotype shorter than maxLengthDel
+    ws = [Window(1000, [hap, "ACGT"], reads_from(hap, 5, 30),       # second haplotype shorter than maxLengthDel; its
+                 hap_vars=[[(20, 22)], [(1, 2), (0, 3)]],           # coverage flags must come back as 0, not stale memory
+                 hap_var_flanks=[[(19, 23, 1)], [(0, 3, 2), (1, 2, 1)]]),
           Window(2000, ["ACGTA", hap], reads_from(hap, 4, 30, start0=2000))]   # hapSize == maxLengthDel is allowed
+    pb0 = pack(ws)
+    arrs, res = alloc_result(pb0, fill=None)
+    for k in ("var_covered", "var_fcov"):
+        arrs[k][:] = 7                                              # host-side poison: every entry has to be overwritten
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(pb0.ctypes_batch()), C.byref(res), 0) == 0
+    assert arrs["var_covered"][:pb0.var_cov_len].max() <= 1 and arrs["var_fcov"][:pb0.var_cov_len].max() <= 1
     pb, got = check(lib, ws, p)
     st = got["status"][:pb.n_pairs]
     assert st[:5].tolist() == [0] * 5 and st[5:10].tolist() == [capi.DD_PAIR_HAPSIZE] * 5

@@ -184,9 +184,10 @@ def test_faster_fuzz(lib, seed, max_hap, max_read, mld):
     model; haplotypes shorter than maxLengthDel make whole haplotypes fail with DD_PAIR_HAPSIZE."""
     from tests.test_gpu_fuzz import make_windows
     rng = np.random.default_rng(3000 + seed)
-    ws = make_windows(rng, 100, max_hap, max_read, min_hap=1)
+    ws = make_windows(rng, 100, max_hap, max_read, min_hap=1, with_vars=(seed % 2 == 1))
     p = capi.params_cli_defaults()
     p.maxLengthDel = mld
+    p.padCover = int(rng.integers(0, 4))
     p.capMapQualFast = float(rng.choice([5.0, 45.0, 200.0]))
     pb = pack(ws)
     assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=8, faster=True), pb)

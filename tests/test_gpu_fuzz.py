@@ -12,7 +12,7 @@ from tests.test_gpu_parity import assert_same, run_host_api
 pytestmark = pytest.mark.gpu
 
 
-def make_windows(rng, n, max_hap, max_read, min_hap):
+def make_windows(rng, n, max_hap, max_read, min_hap, with_vars=False):
     quals = np.concatenate([phred_to_prob(np.arange(0, 45)), [0.5, 0.25, 0.95, 0.951, 0.949]])
     mapqs = [1e-16, 0.3, 0.9, 0.99, 0.9999, 1 - 1e-10, 1 - 1e-16]
     ws = []
@@ -48,7 +48,20 @@ def make_windows(rng, n, max_hap, max_read, min_hap):
                 s = ["A"]
             start = 1000 + off if rng.random() < 0.8 else int(rng.choice([0, 5, 900, 2000, 0xFFFFFFFF, 1000 + len(src)]))
             reads.append(ReadRec("".join(s), rng.choice(quals, len(s)), float(rng.choice(mapqs)), start, unmapped=bool(rng.random() < 0.1)))
-        ws.append(Window(1000, haps, reads))
+        if with_vars:        # random haplotype variants: (startRead, endRead) and (leftFlank, rightFlank, kind) incl. edge values
+            hv, hf = [], []
+            for h in haps:
+                k = int(rng.integers(0, 4))
+                v, f = [], []
+                for _v in range(k):
+                    a = int(rng.integers(-2, len(h) + 2)); b = a + int(rng.integers(0, 9))
+                    v.append((a, b))
+                    fl = int(rng.choice([-1, 0, 1, 2, 3, a - 1, a])); fr = fl + int(rng.integers(0, 12))
+                    f.append((fl, fr, int(rng.integers(0, 3))))
+                hv.append(v); hf.append(f)
+            ws.append(Window(1000, haps, reads, hap_vars=hv, hap_var_flanks=hf))
+        else:
+            ws.append(Window(1000, haps, reads))
     return ws
 
 
@@ -58,7 +71,7 @@ def make_windows(rng, n, max_hap, max_read, min_hap):
                                                               (10, 200, 170, 10, -1), (11, 30, 300, 3, -1)])
 def test_fuzz(lib, seed, max_hap, max_read, mld, bmid):
     rng = np.random.default_rng(1000 + seed)
-    ws = make_windows(rng, 120, max_hap, max_read, min_hap=max(mld, 1))
+    ws = make_windows(rng, 120, max_hap, max_read, min_hap=max(mld, 1), with_vars=(seed % 2 == 0))
     p = capi.params_cli_defaults()
     p.maxLengthDel = mld
     p.bMid = bmid

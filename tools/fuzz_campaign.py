@@ -43,7 +43,8 @@ while time.time() < t_end:
         p.bMid = int(rng.integers(0, 30))
     if kind == 0:
         max_hap = int(rng.choice([40, 62, 126, 190, 254, 400, 755]))   # make_windows adds up to 7 inserted bases
-        ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1)
+        ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1,
+                          with_vars=bool(rng.random() < 0.6))
         pb = pack(ws)
     elif kind == 1:
         pb = synth.generate(int(rng.integers(1, 8)), H=int(rng.integers(1, 17)), R=int(rng.integers(1, 300)),
