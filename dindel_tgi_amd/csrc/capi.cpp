@@ -63,6 +63,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
     const uint32_t NP = 64u * K;
     uint32_t o = 0;
     o = up16(NP + 16);
+    A.lds_off_L = o;  o += 256;                  // byte -> symbol id table
     A.lds_off_E = o;  o += up16((NP + Dt + 2) * 8);
     A.lds_off_N = o;  o += up16((NP + Dt + 2) * 8);
     A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
@@ -368,6 +369,26 @@ int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off
     return DD_SUCCESS;
 }
 
+int dd_build_symbol_lut(const dd_batch *b, uint8_t *out)
+{
+    if (!b || !out || !b->hap_seq_off || !b->win_hap_off) return fail(DD_ERR_INVALID, "null argument");
+    for (int i = 0; i < 256; i++) out[i] = 31;                    // read-only symbol: equal to no haplotype symbol
+    out[(unsigned char)'A'] = 0; out[(unsigned char)'C'] = 1; out[(unsigned char)'G'] = 2; out[(unsigned char)'T'] = 3;
+    out[(unsigned char)'N'] = 4;
+    bool seen[256] = {false};
+    const int64_t n_haps = b->n_windows > 0 ? b->win_hap_off[b->n_windows] : 0;
+    const int64_t nb = n_haps > 0 ? b->hap_seq_off[n_haps] : 0;
+    if (nb > 0 && !b->hap_seq) return fail(DD_ERR_INVALID, "null input array");
+    for (int64_t i = 0; i < nb; i++) seen[(unsigned char)b->hap_seq[i]] = true;
+    int next = 5;
+    for (int c = 0; c < 256; c++) {
+        if (!seen[c] || c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') continue;
+        if (next > 30) return fail(DD_ERR_UNSUPPORTED, "more than 26 distinct non-ACGTN byte values in the haplotypes of one batch");
+        out[c] = (uint8_t)next++;
+    }
+    return DD_SUCCESS;
+}
+
 int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, const double *mapq_table, int n_mapq, double *out)
 {
     int rc = check_params(p);
@@ -553,7 +574,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     A.read_seq_off = b->read_seq_off; A.read_seq = b->read_seq; A.read_qidx = b->read_qidx; A.read_mqidx = b->read_mqidx;
     A.read_start = b->read_start; A.read_flags = b->read_flags;
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
-    A.win_varcov_off = b->win_varcov_off; A.tables = b->tables;
+    A.win_varcov_off = b->win_varcov_off; A.tables = b->tables; A.sym_lut = b->sym_lut;
     A.out = *r;
 #ifdef DD_STAMPS
     A.dbg = g_dbg;
@@ -787,11 +808,8 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
         return fail(DD_ERR_INVALID, "quality tables must hold 1..256 entries");
     for (int64_t h = 0; h < sz.n_haps; h++)
         if (b->hap_seq_off[h + 1] - b->hap_seq_off[h] < 1) return fail(DD_ERR_INVALID, "empty haplotype");
-    for (int64_t i = 0; i < sz.hap_bases; i++) {
-        const char c = b->hap_seq[i];
-        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N'))
-            return fail(DD_ERR_UNSUPPORTED, "haplotype bases must be A, C, G, T or N");
-    }
+    uint8_t sym_lut[256];
+    if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
     for (int64_t q = 0; q < sz.n_reads; q++) {
         if (b->read_seq_off[q + 1] - b->read_seq_off[q] < 1) return fail(DD_ERR_INVALID, "empty read");
         if (b->read_mqidx[q] >= b->n_mapq) return fail(DD_ERR_INVALID, "read_mqidx out of range");
@@ -904,6 +922,7 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
     if ((rc = dev.upload(&db.win_hpos_off, (const int64_t *)hpos_off.data(), hpos_off.size()))) return rc;
     if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
     if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
+    if ((rc = dev.upload(&db.sym_lut, (const uint8_t *)sym_lut, (size_t)256))) return rc;
     if (!single_class)
         for (auto &hc : hcls)
             if (!hc.haps.empty() && (rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;

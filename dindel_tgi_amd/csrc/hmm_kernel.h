@@ -45,6 +45,7 @@ struct KernelArgs {
     const int32_t *hap_window;
     const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
     const double *tables;
+    const uint8_t *sym_lut;              /* byte -> symbol id (dd_build_symbol_lut); NULL = A,C,G,T,N only */
     dd_result out;
     /* params */
     int32_t D, maxLengthDel, padCover, bMid, maxMismatch;
@@ -60,7 +61,7 @@ struct KernelArgs {
     void *bt_scratch; int32_t bt_rows;   /* GBT builds: per-wave back-pointer tiles in HBM, rows = max read length */
     unsigned long long *dbg;   /* diagnostic builds only (DD_STAMPS); NULL otherwise */
     /* LDS layout (bytes) */
-    uint32_t lds_off_E, lds_off_N, lds_off_Q, lds_off_C, lds_off_Y, lds_shared_bytes, lds_wave_bytes;
+    uint32_t lds_off_L, lds_off_E, lds_off_N, lds_off_Q, lds_off_C, lds_off_Y, lds_shared_bytes, lds_wave_bytes;
     int32_t n_qual;
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
 };

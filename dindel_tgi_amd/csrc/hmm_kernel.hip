@@ -46,14 +46,20 @@ namespace ddk {
 #endif
 #define NEG_INF (-__builtin_huge_val())
 
-__device__ __forceinline__ int base_code(unsigned char ch)
+// Symbols.  The reference compares bases as characters (hap[y]==nuc, ObservationModelFB.cpp:246; read.seq[b]!=hap.seq[s-1],
+// :1410) and treats only a haplotype 'N' as a wildcard, so any byte may occur on either side (IUPAC codes, soft-masked
+// lower case).  Bytes are mapped to symbol ids through a 256-entry table (dd_build_symbol_lut): A,C,G,T -> 0..3, N -> 4,
+// every other byte present in a haplotype of the batch -> 5..30, every remaining byte -> 31 (a read-only symbol: equal to no
+// haplotype symbol).  Equal ids <=> equal characters wherever a haplotype is involved.  Without a table: A,C,G,T,N and 31.
+#define DD_SYM_N 4
+#define DD_SYM_PAD 255   /* padded state: matches nothing */
+__device__ __forceinline__ int builtin_symbol(unsigned ch)
 {
-    // A C G T -> 0..3, N -> 4, anything else -> 5 (reads only; haplotypes are validated to ACGTN)
-    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : 5;
+    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? DD_SYM_N : 31;
 }
 
-// hap[y]=='N' || hap[y]==nuc  (ObservationModelFB.cpp:246); state code 4 = 'N' or LO/RO (always eq)
-__device__ __forceinline__ bool code_match(int scode, int rcol) { return scode == 4 || scode == rcol; }
+// hap[y]=='N' || hap[y]==nuc  (ObservationModelFB.cpp:246); state symbol 4 = 'N' or LO/RO (always eq)
+__device__ __forceinline__ bool code_match(int scode, int rcol) { return scode == DD_SYM_N || scode == rcol; }
 
 // exact ObservationModelFBMax::updateMax (ObservationModelFB.cpp:877-888) for the few special states
 __device__ __forceinline__ void update_max(double &dest, int &idx, int &code, double v, int newIdx, int newCode)
@@ -163,7 +169,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     const double lLL = T[TC_LLL], lFL = T[TC_LFL], II = T[TC_II], NI = T[TC_NI], NN = T[TC_NN];
 
     // ---------------- shared (per haplotype) region ----------------
-    unsigned char *sc = smem;                                   // [NP+16] state codes
+    unsigned char *sc = smem;                                   // [NP+16] state symbols
+    unsigned char *shLut = smem + P.lds_off_L;                  // [256] byte -> symbol id
     double *shE = reinterpret_cast<double *>(smem + P.lds_off_E);  // [NP+D+2] logProbError per state
     double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+D+2] logProbNoError per state
     double *shQ = reinterpret_cast<double *>(smem + P.lds_off_Q);  // [n_qual][4] eq, uq, log10(1-q), q
@@ -197,6 +204,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         bt = reinterpret_cast<btword_t *>(wbase + P.lds_off_bt);
 
     for (int i = tid; i < 4 * P.n_qual; i += nthr) shQ[i] = T[T_QUAL + i];
+    for (int i = tid; i < 256; i += nthr) shLut[i] = P.sym_lut ? P.sym_lut[i] : (unsigned char)builtin_symbol((unsigned)i);
     // pads of the wave-private rows: written once, never touched again
     if (lane == 0) { rowI[0] = NEG_INF; rowI[1 + NP] = NEG_INF; }
     STAMP_INIT;
@@ -220,9 +228,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
 
     // ---- per-haplotype setup: state codes + homopolymer indel-error logs (setupTransitionProbs :1675-1703)
     for (int s = tid; s < NP + 16; s += nthr) {
-        int code = 6;                                // padded state: matches nothing
-        if (s == 0 || s == RO) code = 4;             // LO / RO: emission is always eq (:237-241)
-        else if (s < RO) code = base_code((unsigned char)P.hap_seq[hs_off + s - 1]);
+        int code = DD_SYM_PAD;                       // padded state: matches nothing
+        if (s == 0 || s == RO) code = DD_SYM_N;      // LO / RO: emission is always eq (:237-241)
+        else if (s < RO) code = shLut[(unsigned char)P.hap_seq[hs_off + s - 1]];
         sc[s] = (unsigned char)code;
     }
     for (int s = tid; s < NP + D + 2; s += nthr) {
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         niDec[k] = (x == 0) ? NEG_INF : NI;         // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
         uint32_t mo = 0;
 #pragma unroll
-        for (int col = 0; col < 5; col++)
+        for (int col = 0; col < 32; col++)
             if (valid && code_match(sc[x], col)) mo |= 1u << col;
         mOwn[k] = mo;
     }
@@ -341,7 +349,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         // ---- stage the read: base codes + emission logs (setupReadObservationPotentials :220-252) ----
         for (int b = lane; b < L; b += 64) {
             const int qi = P.read_qidx[so + b];
-            rdC[b] = (unsigned char)base_code((unsigned char)P.read_seq[so + b]);
+            rdC[b] = shLut[(unsigned char)P.read_seq[so + b]];
             rdQ[b] = (unsigned char)qi;
             rdE[2 * b] = shQ[4 * qi];
             rdE[2 * b + 1] = shQ[4 * qi + 1];
@@ -382,7 +390,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             };
             for (int b = L - 1; b > bMid; b--) {
                 const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
-                const int col = rdC[b] > 4 ? 4 : rdC[b];
+                const int col = rdC[b];
                 double v[D + K], ov[D + K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
@@ -503,7 +511,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             }
             for (int b = 1; b <= bMid; b++) {
                 const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
-                const int col = rdC[b - 1] > 4 ? 4 : rdC[b - 1];
+                const int col = rdC[b - 1];
                 double v[D + K], ov[D + K];
                 // publish slice b-1 (value + this state's emission for read base b-1) for the neighbours
 #pragma unroll
@@ -598,7 +606,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         // ================= join at bMid: calcLikelihoodFromLastSlice (:1075-1144) + computeBMidPrior (:268-305)
         {
             const double eq = rdE[2 * bMid], uq = rdE[2 * bMid + 1];
-            const int col = rdC[bMid] > 4 ? 4 : rdC[bMid];
+            const int col = rdC[bMid];
             const int mqi = P.read_mqidx[r];
             const double prOff0 = T[T_MAPQ + 4 * mqi + 0], prOff1 = T[T_MAPQ + 4 * mqi + 1];
             const double prOn0 = T[T_MAPQ + 4 * mqi + 2], prOn1 = T[T_MAPQ + 4 * mqi + 3];
@@ -819,7 +827,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                             if (s >= 1 && s <= Hs) {                          // on a haplotype base (no inserted states here)
                                 const int hb = s - 1;
                                 const int hc = sc[s];
-                                mm = hb >= left && hb <= right && (int)rdC[b] != hc && (kind == 2 || hc != 4);   // 'N' exempt for DEL (:1992)
+                                mm = hb >= left && hb <= right && (int)rdC[b] != hc && (kind == 2 || hc != DD_SYM_N);   // 'N' exempt for DEL (:1992)
                             }
                         }
                         nmm += __popcll(__ballot(mm));

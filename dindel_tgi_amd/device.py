@@ -51,6 +51,10 @@ class DeviceBatch:
         t["win_hpos_off"] = _to_dev(ho, self.device)
         t["win_varcov_off"] = _to_dev(vo, self.device)
         t["tables"] = _to_dev(tables, self.device)
+        lut = np.zeros(256, np.uint8)
+        if lib.dd_build_symbol_lut(C.byref(hb), lut.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+            raise RuntimeError("dd_build_symbol_lut: " + capi.last_error())
+        t["sym_lut"] = _to_dev(lut, self.device)
         if pb.hap_var_flank is not None and len(pb.hap_var_flank):
             t["hap_var_flank"] = _to_dev(pb.hap_var_flank, self.device)
         self.t = t

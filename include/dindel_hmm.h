@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 5
+#define DD_ABI_VERSION 6
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -176,6 +176,12 @@ void dd_release_cache(void);
 int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
                     const double *mapq_table, int n_mapq, double *out);
 
+/* Bases are compared as characters, as in the reference (hap[y]==nuc || hap[y]=='N', ObservationModelFB.cpp:246): any
+ * byte may occur in reads and haplotypes (IUPAC codes, soft-masked lower case).  This builds the byte -> symbol-id table
+ * the main kernel uses (A,C,G,T -> 0..3, N -> 4, other bytes present in a haplotype of the batch -> 5..30, the rest -> 31);
+ * out[256].  More than 26 distinct non-ACGTN haplotype bytes in one batch -> DD_ERR_UNSUPPORTED. */
+int dd_build_symbol_lut(const dd_batch *b, uint8_t *out);
+
 /* Host-side derived index arrays the kernels need, sized by the caller:
  * hap_window[n_haps], win_pair_off[n_windows+1], win_hpos_off[n_windows+1], win_varcov_off[n_windows+1] */
 int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off,
@@ -192,6 +198,7 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
     const double  *tables;          /* DD_TABLE_DOUBLES doubles from dd_build_tables               */
     int32_t n_qual, n_mapq;
     const int32_t *hap_var_flank;   /* optional, see dd_batch */
+    const uint8_t *sym_lut;         /* optional: 256 bytes from dd_build_symbol_lut; NULL = haplotypes hold A,C,G,T,N only */
 } dd_device_batch;
 
 /* bytes of device scratch dd_launch_device needs for this shape (0 if none) */

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(capi.EXPORTS), (names, capi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.dd_abi_version() == 5
+    assert lib.dd_abi_version() == 6
     assert lib.dd_kernel_name().decode() == "dd_hmm_kernel"
 
 
@@ -107,9 +107,10 @@ def test_no_cpu_fallback_and_validation(lib):
         assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == capi.DD_ERR_NO_DEVICE
         assert "no CPU fallback" in capi.last_error()
     # validation happens before any device work
-    bad = _one_window(hap="ACGTRCGTACGT")
+    bad = _one_window(hap="".join(chr(c) for c in range(97, 97 + 27)))      # 27 distinct non-ACGTN haplotype bytes
     bb = bad.ctypes_batch()
     assert lib.dd_compute_likelihoods(C.byref(p), C.byref(bb), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    assert "26 distinct" in capi.last_error()
     p2 = capi.params_cli_defaults(); p2.mapUnmappedReads = 1
     assert lib.dd_compute_likelihoods(C.byref(p2), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
     p3 = capi.params_cli_defaults(); p3.maxLengthDel = 12
@@ -123,3 +124,15 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libdindel_hmm.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         capi.load()
+
+
+def test_symbol_lut(lib):
+    """dd_build_symbol_lut: A,C,G,T,N fixed; other haplotype bytes get ids 5..30 in byte order; all remaining bytes 31."""
+    pb = pack([Window(1000, ["ACGTNRYacgtn", "MMKA"], [ReadRec("ACGTWS", [0.999] * 6, 0.9999, 1000)])])
+    b = pb.ctypes_batch()
+    lut = np.zeros(256, np.uint8)
+    assert lib.dd_build_symbol_lut(C.byref(b), lut.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert [int(lut[ord(c)]) for c in "ACGTN"] == [0, 1, 2, 3, 4]
+    others = sorted(set("RYacgtnMK"))
+    assert [int(lut[ord(c)]) for c in others] == list(range(5, 5 + len(others)))
+    assert int(lut[ord("W")]) == 31 and int(lut[ord("S")]) == 31 and int(lut[0]) == 31

@@ -277,3 +277,30 @@ def test_mapping_quality_ladder_and_cap(lib):
         reads.append(ReadRec(mutate(good, 0.15), [0.99] * 100, mq, 1010))
     pb, got = check(lib, [Window(1000, [hap, hap[:60] + hap[63:]], reads)])
     assert got["offHap"][:pb.n_pairs].any() and not got["offHap"][:pb.n_pairs].all()
+
+
+def test_iupac_and_soft_masked_haplotype_bytes(lib):
+    """The reference compares characters: a haplotype 'R' matches a read 'R' and nothing else, lower case differs from
+    upper case, only a haplotype 'N' is a wildcard.  The kernel works on symbol ids from dd_build_symbol_lut."""
+    alpha = "ACGTNRYKMacgtn"
+    wins = []
+    for i in range(8):
+        hap = "".join(RNG.choice(list(alpha), int(RNG.integers(30, 150)), p=[.2, .2, .2, .2, .03, .02, .02, .01, .01, .03, .03, .02, .02, .01]))
+        hap2 = hap[:20] + hap[23:]
+        reads = []
+        for _ in range(12):
+            src = hap if RNG.random() < 0.5 else hap2
+            L = int(RNG.integers(10, 80))
+            off = int(RNG.integers(-5, max(1, len(src) - 10)))
+            s = "".join(src[j] if 0 <= j < len(src) else RNG.choice(list("ACGT")) for j in range(off, off + L))
+            s = "".join(c if RNG.random() > 0.05 else RNG.choice(list("ACGTNRWSacg")) for c in s)
+            reads.append(ReadRec(s, phred_to_prob(RNG.integers(2, 42, L)), 0.999, 1000 + off))
+        wins.append(Window(1000, [hap, hap2], reads, hap_vars=[[], [(19, 20)]], hap_var_flanks=[[], [(19, 20, 1)]]))
+    for p in (capi.params_cli_defaults(), capi.params_struct_defaults()):
+        pb, got = check(lib, wins, p)
+        assert got["numMismatch"][:pb.n_pairs].any()
+    # the --faster model compares raw bytes as well
+    from tests.test_gpu_faster import assert_same_faster, run_faster
+    pb = pack(wins)
+    p = capi.params_cli_defaults()
+    assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=8, faster=True), pb)
