@@ -17,7 +17,7 @@ def make_windows(rng, n, max_hap, max_read, min_hap, with_vars=False):
     mapqs = [1e-16, 0.3, 0.9, 0.99, 0.9999, 1 - 1e-10, 1 - 1e-16]
     ws = []
     for _ in range(n):
-        alpha = list(rng.choice(["A", "AC", "ACG", "ACGT", "ACGTN", "AT"], 1)[0])
+        alpha = list(rng.choice(["A", "AC", "ACG", "ACGT", "ACGTN", "AT", "ACGTRYn"], 1)[0])
         hl = int(rng.integers(min_hap, max_hap + 1))
         ref = "".join(rng.choice(alpha, hl))
         if "N" not in alpha and rng.random() < 0.2:                       # a run of N (changeINStoN)

@@ -56,8 +56,24 @@ while time.time() < t_end:
                             L=int(rng.choice([36, 76, 100])), hap_len=int(rng.integers(40, 170)), seed=seed,
                             mixed_quals=True, sub_rate=float(rng.choice([1e-3, 0.01])))
     try:
-        assert_same(run_host_api(lib, p, pb), _oracle.batch(p, pb, nthreads=16), pb)
-        assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=16, faster=True), pb)
+        got = run_host_api(lib, p, pb)
+        assert_same(got, _oracle.batch(p, pb, nthreads=16), pb)
+        gotf = run_faster(lib, p, pb)
+        assert_same_faster(gotf, _oracle.batch(p, pb, nthreads=16, faster=True), pb)
+        if rnd % 4 == 0:            # device-pointer entry points (one batch-wide plan) against the host path (length classes)
+            from dindel_tgi_amd.device import DeviceBatch
+            import torch
+            dev = DeviceBatch(pb, p, "cuda:0")
+            ok = got["status"][:pb.n_pairs] == 0
+            for launch, ref in ((dev.launch, got), (dev.launch_faster, gotf)):
+                launch()
+                torch.cuda.synchronize()
+                res = dev.results()
+                okm = ref["status"][:pb.n_pairs] == 0
+                for k in ("ll", "status", "firstBase", "lastBase", "numIndels", "offHap"):
+                    assert np.array_equal(res[k][:pb.n_pairs][okm], ref[k][:pb.n_pairs][okm]), ("device path", k)
+                assert np.array_equal(res["onHap"][:pb.n_reads], ref["onHap"][:pb.n_reads]), "device path onHap"
+            del dev
     except AssertionError as e:
         print("MISMATCH at seed", seed, "kind", kind, "params", {f: getattr(p, f) for f, _ in p._fields_}, flush=True)
         print(str(e)[:2000], flush=True)
