@@ -21,6 +21,14 @@ class ReadRec:
     mapQual: float                 # Read::mapQual (probability)
     start: int                     # uint32_t(read.posStat.first)
     unmapped: bool = False         # bam->core.flag & BAM_FUNMAP
+    # mate / library inputs of the insert-size prior (mapUnmappedReads; ObservationModelFB.cpp:279-292)
+    paired: bool = False           # read.isPaired()
+    mate_unmapped: bool = False    # read.mateIsUnmapped()
+    mate_reverse: bool = False     # read.mateIsReverse()
+    mate_same_tid: bool = False    # bam->core.tid == bam->core.mtid
+    mate_pos: int = -1             # read.matePos
+    mate_len: int = -1             # read.mateLen (-1 unknown)
+    lib: int = 0                   # index into the batch's libraries
 
 
 @dataclass
@@ -49,8 +57,13 @@ class PackedBatch:
               "read_seq_off", "read_seq", "read_qidx", "read_mqidx", "read_start", "read_flags",
               "qual_table", "mapq_table"]
 
-    def __init__(self, hap_var_flank=None, **arrays):
+    def __init__(self, hap_var_flank=None, mate=None, **arrays):
         self.hap_var_flank = None if hap_var_flank is None else np.ascontiguousarray(hap_var_flank, dtype=np.int32)
+        # mate: None, or dict(read_mate_pos, read_mate_len, read_lib, lib_off, lib_prob, lib_p95) for mapUnmappedReads
+        self.mate = None
+        if mate is not None:
+            dtm = dict(read_mate_pos=np.int32, read_mate_len=np.int32, read_lib=np.uint8, lib_off=np.int32, lib_prob=np.float64, lib_p95=np.float64)
+            self.mate = {k: np.ascontiguousarray(mate[k], dtype=dtm[k]) for k in dtm}
         self.a = {}
         dt = dict(win_hap_off=np.int32, win_read_off=np.int32, win_hap_start=np.uint32, hap_seq_off=np.int32,
                   hap_seq=np.uint8, hap_var_off=np.int32, hap_var=np.int32, read_seq_off=np.int32,
@@ -109,6 +122,15 @@ class PackedBatch:
         b.mapq_table = _ptr(a["mapq_table"], capi.c_f64p)
         if self.hap_var_flank is not None and len(self.hap_var_flank):
             b.hap_var_flank = _ptr(self.hap_var_flank, capi.c_i32p)
+        if self.mate is not None:
+            m = self.mate
+            b.read_mate_pos = _ptr(m["read_mate_pos"], capi.c_i32p)
+            b.read_mate_len = _ptr(m["read_mate_len"], capi.c_i32p)
+            b.read_lib = _ptr(m["read_lib"], capi.c_u8p)
+            b.n_libs = len(m["lib_p95"])
+            b.lib_off = _ptr(m["lib_off"], capi.c_i32p)
+            b.lib_prob = _ptr(m["lib_prob"], capi.c_f64p)
+            b.lib_p95 = _ptr(m["lib_p95"], capi.c_f64p)
         return b
 
     def slice_windows(self, w0, w1):
@@ -127,16 +149,20 @@ class PackedBatch:
             read_seq=a["read_seq"][rs0:rs1], read_qidx=a["read_qidx"][rs0:rs1], read_mqidx=a["read_mqidx"][r0:r1],
             read_start=a["read_start"][r0:r1], read_flags=a["read_flags"][r0:r1],
             qual_table=a["qual_table"], mapq_table=a["mapq_table"],
-            hap_var_flank=None if self.hap_var_flank is None else self.hap_var_flank[3 * v0:3 * v1])
+            hap_var_flank=None if self.hap_var_flank is None else self.hap_var_flank[3 * v0:3 * v1],
+            mate=None if self.mate is None else dict(self.mate, read_mate_pos=self.mate["read_mate_pos"][r0:r1],
+                                                     read_mate_len=self.mate["read_mate_len"][r0:r1], read_lib=self.mate["read_lib"][r0:r1]))
 
 
-def pack(windows: Sequence[Window]) -> PackedBatch:
-    """Pack Window objects; dedups base/mapping quality doubles into the <=256-entry tables."""
+def pack(windows: Sequence[Window], libraries=None) -> PackedBatch:
+    """Pack Window objects; dedups base/mapping quality doubles into the <=256-entry tables.
+    libraries: optional list of (probs, p95) — Library::getProb table and getNinetyFifthPctProb() — enables the mate arrays."""
     qmap, mqmap = {}, {}
     win_hap_off, win_read_off, win_hap_start = [0], [0], []
     hap_seq_off, hap_seq, hap_var_off, hap_var = [0], [], [0], []
     hap_var_flank, any_flank = [], any(w.hap_var_flanks is not None for w in windows)
     read_seq_off, read_seq, read_qidx, read_mqidx, read_start, read_flags = [0], [], [], [], [], []
+    mate_pos, mate_len, read_lib = [], [], []
     for w in windows:
         win_hap_start.append(w.hap_start & 0xFFFFFFFF)
         for hi, h in enumerate(w.haps):
@@ -166,7 +192,9 @@ def pack(windows: Sequence[Window]) -> PackedBatch:
                 mqmap[mq] = len(mqmap)
             read_mqidx.append(mqmap[mq])
             read_start.append(int(r.start) & 0xFFFFFFFF)
-            read_flags.append(1 if r.unmapped else 0)
+            read_flags.append((1 if r.unmapped else 0) | (2 if r.paired else 0) | (4 if r.mate_unmapped else 0) |
+                              (8 if r.mate_reverse else 0) | (16 if r.mate_same_tid else 0))
+            mate_pos.append(int(r.mate_pos)); mate_len.append(int(r.mate_len)); read_lib.append(int(r.lib))
         win_read_off.append(win_read_off[-1] + len(w.reads))
     if len(qmap) > 256 or len(mqmap) > 256:
         raise ValueError("more than 256 distinct base or mapping qualities in one batch")
@@ -183,7 +211,12 @@ def pack(windows: Sequence[Window]) -> PackedBatch:
         read_qidx=np.array(read_qidx, dtype=np.uint8), read_mqidx=np.array(read_mqidx, dtype=np.uint8),
         read_start=np.array(read_start, dtype=np.uint32), read_flags=np.array(read_flags, dtype=np.uint8),
         qual_table=qt, mapq_table=mt,
-        hap_var_flank=np.array(hap_var_flank, dtype=np.int32) if any_flank else None)
+        hap_var_flank=np.array(hap_var_flank, dtype=np.int32) if any_flank else None,
+        mate=None if libraries is None else dict(
+            read_mate_pos=mate_pos, read_mate_len=mate_len, read_lib=read_lib,
+            lib_off=np.concatenate([[0], np.cumsum([len(pr) for pr, _ in libraries])]),
+            lib_prob=np.concatenate([np.asarray(pr, np.float64) for pr, _ in libraries]),
+            lib_p95=[p95 for _, p95 in libraries]))
 
 
 RESULT_DTYPES = dict(ll=np.float64, llOn=np.float64, llOff=np.float64, mLogBQ=np.float64, offHap=np.uint8,

@@ -18,7 +18,8 @@ c_u8p = C.POINTER(C.c_uint8)
 c_i16p = C.POINTER(C.c_int16)
 c_f64p = C.POINTER(C.c_double)
 
-DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 64
+DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 2 * 256 + 64
+DD_READ_UNMAPPED, DD_READ_PAIRED, DD_READ_MATE_UNMAPPED, DD_READ_MATE_REVERSE, DD_READ_MATE_SAME_TID = 1, 2, 4, 8, 16
 
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
 DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS = 0, 1, 2, 3
@@ -58,7 +59,9 @@ class dd_batch(C.Structure):
                 ("read_seq_off", c_i32p), ("read_seq", C.c_char_p), ("read_qidx", c_u8p), ("read_mqidx", c_u8p),
                 ("read_start", c_u32p), ("read_flags", c_u8p),
                 ("n_qual", C.c_int32), ("qual_table", c_f64p),
-                ("n_mapq", C.c_int32), ("mapq_table", c_f64p), ("hap_var_flank", c_i32p)]
+                ("n_mapq", C.c_int32), ("mapq_table", c_f64p), ("hap_var_flank", c_i32p),
+                ("read_mate_pos", c_i32p), ("read_mate_len", c_i32p), ("read_lib", c_u8p),
+                ("n_libs", C.c_int32), ("lib_off", c_i32p), ("lib_prob", c_f64p), ("lib_p95", c_f64p)]
 
 
 RESULT_FIELDS = [("ll", c_f64p), ("llOn", c_f64p), ("llOff", c_f64p), ("mLogBQ", c_f64p),
@@ -88,7 +91,9 @@ class dd_device_batch(C.Structure):
                 ("read_start", C.c_void_p), ("read_flags", C.c_void_p),
                 ("hap_window", C.c_void_p), ("win_pair_off", C.c_void_p), ("win_hpos_off", C.c_void_p),
                 ("win_varcov_off", C.c_void_p), ("tables", C.c_void_p),
-                ("n_qual", C.c_int32), ("n_mapq", C.c_int32), ("hap_var_flank", C.c_void_p), ("sym_lut", C.c_void_p)]
+                ("n_qual", C.c_int32), ("n_mapq", C.c_int32), ("hap_var_flank", C.c_void_p), ("sym_lut", C.c_void_p),
+                ("read_mate_pos", C.c_void_p), ("read_mate_len", C.c_void_p), ("read_lib", C.c_void_p),
+                ("lib_off", C.c_void_p), ("lib_logprob", C.c_void_p), ("lib_log95", C.c_void_p)]
 
 
 class dd_device_result(C.Structure):
@@ -97,7 +102,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
-           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -132,6 +137,7 @@ def load():
     lib.dd_release_cache.restype = None
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_symbol_lut.argtypes = [C.POINTER(dd_batch), C.POINTER(C.c_uint8)]
+    lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]
     lib.dd_workspace_bytes.restype = C.c_size_t

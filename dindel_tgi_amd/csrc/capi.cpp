@@ -162,7 +162,6 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
 int check_params(const dd_params *p)
 {
     if (!p) return fail(DD_ERR_INVALID, "null params");
-    if (p->mapUnmappedReads) return fail(DD_ERR_UNSUPPORTED, "mapUnmappedReads needs the Library insert-size pmf (out of scope)");
     if (p->forceReadOnHaplotype) return fail(DD_ERR_UNSUPPORTED, "forceReadOnHaplotype is not on the production path (DInDel.cpp:1446 only)");
     if (p->maxLengthDel < 0 || p->maxLengthDel > DD_MAX_LENGTH_DEL) return fail(DD_ERR_UNSUPPORTED, "maxLengthDel outside [0,11]");
     if (!(p->pError > 0.0 && p->pError < 1.0)) return fail(DD_ERR_INVALID, "pError outside (0,1)");
@@ -369,6 +368,24 @@ int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off
     return DD_SUCCESS;
 }
 
+int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log95_out)
+{
+    if (!b || !logprob_out || !log95_out) return fail(DD_ERR_INVALID, "null argument");
+    if (b->n_libs < 1 || b->n_libs > 256 || !b->lib_off || !b->lib_prob || !b->lib_p95)
+        return fail(DD_ERR_INVALID, "mapUnmappedReads needs 1..256 libraries (lib_off, lib_prob, lib_p95)");
+    if (b->lib_off[0] != 0) return fail(DD_ERR_INVALID, "lib_off[0] must be 0");
+    for (int i = 0; i < b->n_libs; i++) {
+        if (b->lib_off[i + 1] - b->lib_off[i] < 1) return fail(DD_ERR_INVALID, "empty library table");
+        if (!(b->lib_p95[i] > 0.0)) return fail(DD_ERR_INVALID, "library probabilities must be positive");
+        log95_out[i] = log(b->lib_p95[i]);                                   // ObservationModelFB.cpp:289
+    }
+    for (int i = 0; i < b->lib_off[b->n_libs]; i++) {
+        if (!(b->lib_prob[i] > 0.0)) return fail(DD_ERR_INVALID, "library probabilities must be positive");
+        logprob_out[i] = log(b->lib_prob[i]);                                // :285, :287
+    }
+    return DD_SUCCESS;
+}
+
 int dd_build_symbol_lut(const dd_batch *b, uint8_t *out)
 {
     if (!b || !out || !b->hap_seq_off || !b->win_hap_off) return fail(DD_ERR_INVALID, "null argument");
@@ -430,6 +447,16 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
             dst[0 + k] = log(pOffFirst) + logpIns + pinsert;          // prior[i*numS+0]
             dst[2 + k] = pinsert + log((1.0 - pOffFirst)) + logpIns;  // prior[i*numS+x], 1<=x<=hapSize
         }
+    }
+    // insert-size prior path (mapUnmappedReads): the separate terms of computeBMidPrior — :272-276, :296-303
+    out[TC_PINS + 0] = log(1.0 - exp(logpInsgNoIns));
+    for (int i = -1; i < n_mapq; i++) {
+        const double mapQual = (i < 0) ? (1.0 - 1e-10) : mapq_table[i];
+        double mq = 1.0 - mapQual;
+        if (-10.0 * log10(mq) > p->mapQualThreshold) mq = pow(10.0, -p->mapQualThreshold / 10.0);
+        double *dst = (i < 0) ? &out[TC_PINS + 1] : &out[T_MAPQ2 + 2 * i];
+        dst[0] = log(mq);
+        dst[1] = log((1.0 - mq));
     }
     // --faster model: ObservationModelS::setupReadLikelihoods / SStateHMM constants — reference Faster.cpp:117-124, :300-352
     out[TC_FAST + 0] = log(1.0 - p->pError);
@@ -575,6 +602,12 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     A.read_start = b->read_start; A.read_flags = b->read_flags;
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
     A.win_varcov_off = b->win_varcov_off; A.tables = b->tables; A.sym_lut = b->sym_lut;
+    if (p->mapUnmappedReads && g_model == 0) {              // the --faster model has no insert-size prior
+        if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib || !b->lib_off || !b->lib_logprob || !b->lib_log95)
+            return fail(DD_ERR_INVALID, "mapUnmappedReads needs the mate arrays and the library log tables");
+        A.read_mate_pos = b->read_mate_pos; A.read_mate_len = b->read_mate_len; A.read_lib = b->read_lib;
+        A.lib_off = b->lib_off; A.lib_logprob = b->lib_logprob; A.lib_log95 = b->lib_log95;
+    }
     A.out = *r;
 #ifdef DD_STAMPS
     A.dbg = g_dbg;
@@ -810,6 +843,17 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
         if (b->hap_seq_off[h + 1] - b->hap_seq_off[h] < 1) return fail(DD_ERR_INVALID, "empty haplotype");
     uint8_t sym_lut[256];
     if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
+    std::vector<double> lib_logprob, lib_log95;
+    if (p->mapUnmappedReads && g_model == 0) {
+        if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib)
+            return fail(DD_ERR_INVALID, "mapUnmappedReads needs read_mate_pos, read_mate_len and read_lib");
+        if (b->n_libs < 1 || !b->lib_off) return fail(DD_ERR_INVALID, "mapUnmappedReads needs the library tables");
+        lib_logprob.resize((size_t)(b->lib_off[b->n_libs] > 0 ? b->lib_off[b->n_libs] : 1));
+        lib_log95.resize((size_t)b->n_libs);
+        if ((rc = dd_build_library_tables(b, lib_logprob.data(), lib_log95.data()))) return rc;
+        for (int64_t q = 0; q < sz.n_reads; q++)
+            if (b->read_lib[q] >= b->n_libs) return fail(DD_ERR_INVALID, "read_lib out of range");
+    }
     for (int64_t q = 0; q < sz.n_reads; q++) {
         if (b->read_seq_off[q + 1] - b->read_seq_off[q] < 1) return fail(DD_ERR_INVALID, "empty read");
         if (b->read_mqidx[q] >= b->n_mapq) return fail(DD_ERR_INVALID, "read_mqidx out of range");
@@ -899,7 +943,8 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
     const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
     const size_t in_bytes = (size_t)(W + 1) * (4 + 4 + 8 + 8 + 8) + (size_t)W * 4 + (size_t)(sz.n_haps + 1) * 8 + (size_t)sz.hap_bases +
                             (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 20 +
-                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 40 * 256;
+                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 48 * 256 +
+                            (lib_log95.empty() ? 0 : (size_t)sz.n_reads * 9 + (lib_logprob.size() + lib_log95.size()) * 8 + (size_t)(b->n_libs + 1) * 4);
     const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + 2 * (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
     const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
     DeviceCtx &ctx = g_ctx.c;
@@ -923,6 +968,14 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
     if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
     if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
     if ((rc = dev.upload(&db.sym_lut, (const uint8_t *)sym_lut, (size_t)256))) return rc;
+    if (!lib_log95.empty()) {
+        if ((rc = dev.upload(&db.read_mate_pos, b->read_mate_pos, (size_t)sz.n_reads))) return rc;
+        if ((rc = dev.upload(&db.read_mate_len, b->read_mate_len, (size_t)sz.n_reads))) return rc;
+        if ((rc = dev.upload(&db.read_lib, b->read_lib, (size_t)sz.n_reads))) return rc;
+        if ((rc = dev.upload(&db.lib_off, b->lib_off, (size_t)b->n_libs + 1))) return rc;
+        if ((rc = dev.upload(&db.lib_logprob, (const double *)lib_logprob.data(), lib_logprob.size()))) return rc;
+        if ((rc = dev.upload(&db.lib_log95, (const double *)lib_log95.data(), lib_log95.size()))) return rc;
+    }
     if (!single_class)
         for (auto &hc : hcls)
             if (!hc.haps.empty() && (rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;

@@ -19,12 +19,14 @@ enum {
     TC_NDEF = 7,  /* log(1-1e-5)                 :1679 */
     TC_BQT = 8,   /* checkBaseQualThreshold */
     TC_HMQ = 12,  /* 4 doubles: bMid prior for mapQual = 1-1e-10 (:1093): off/noins, off/ins, on/noins, on/ins */
+    TC_PINS = 21, /* insert-size prior path (mapUnmappedReads): log(1-exp(log pError)), then for mapQual = 1-1e-10: log(pOff), log(1-pOff) */
     TC_FAST = 16, /* --faster model (Faster.cpp:300-352): log(1-pError), log(pError), log(1-exp(-0.25)), log(1-1e-10), log(1e-10) */
     T_QUAL = 32,                          /* 4 per quality: eq, uq (:232-234), log10(1-q) (:1406), q */
     T_MAPQ = T_QUAL + 4 * DD_MAX_QUAL_TABLE, /* 4 per mapping quality: prior off/noins, off/ins, on/noins, on/ins (:296-303) */
     T_HP = T_MAPQ + 4 * DD_MAX_QUAL_TABLE,   /* 2 per run length: log(perr(len)), log(1-perr(len)) (ReadIndelErrorModel.hpp:36-50) */
     T_MAPQF = T_HP + 2 * DD_HP_TABLE,         /* --faster: 2 per mapping quality: log(1-pOffFirst), log(pOffFirst) with capMapQualFast (Faster.cpp:117-124) */
-    T_END = T_MAPQF + 2 * DD_MAX_QUAL_TABLE
+    T_MAPQ2 = T_MAPQF + 2 * DD_MAX_QUAL_TABLE, /* insert-size prior path: 2 per mapping quality: log(pOffFirst), log(1-pOffFirst) (:296-303) */
+    T_END = T_MAPQ2 + 2 * DD_MAX_QUAL_TABLE
 };
 
 namespace ddk {
@@ -46,6 +48,9 @@ struct KernelArgs {
     const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
     const double *tables;
     const uint8_t *sym_lut;              /* byte -> symbol id (dd_build_symbol_lut); NULL = A,C,G,T,N only */
+    /* mapUnmappedReads: mate arrays + library log tables; read_mate_pos == NULL switches the insert-size prior off */
+    const int32_t *read_mate_pos, *read_mate_len; const uint8_t *read_lib;
+    const int32_t *lib_off; const double *lib_logprob, *lib_log95;
     dd_result out;
     /* params */
     int32_t D, maxLengthDel, padCover, bMid, maxMismatch;

@@ -615,16 +615,49 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             double vA[K], vI[K], hA[K], hI[K];
             double *scanA = reinterpret_cast<double *>(rowA), *scanI = scanA + NP;   // near-tie replay scratch (the slice buffer is free now)
             double on = NEG_INF;
+            // Insert-size prior of a paired read whose mate is mapped on the same chromosome (mapUnmappedReads,
+            // computeBMidPrior :279-292): pinsert[x] = log P_library(|distance between the read start implied by "base bMid
+            // sits on haplotype base x" and the mate|), pinsert[LO] = log of the library's 95th-percentile probability.
+            // prior[on, x] = (pinsert[x] + log(1-pOff)) + logpIns;  prior[LO] = (log(pOff) + logpIns) + pinsert[LO]  (:296-303)
+            bool usePin = false;
+            int pinBase = 0, pinMax = 1, pinD0 = 0;
+            if (P.read_mate_pos) {
+                const int fl = P.read_flags[r], mlen = P.read_mate_len[r];
+                usePin = (fl & DD_READ_PAIRED) && !(fl & DD_READ_MATE_UNMAPPED) && mlen != -1 && (fl & DD_READ_MATE_SAME_TID);
+                if (usePin) {
+                    const int lib = P.read_lib[r];
+                    pinBase = P.lib_off[lib];
+                    pinMax = P.lib_off[lib + 1] - pinBase;
+                    // all int arithmetic, as in the reference (hapStart, bMid, readSize are ints there)
+                    pinD0 = (fl & DD_READ_MATE_REVERSE) ? (int)hapStart - bMid - (P.read_mate_pos[r] + mlen)
+                                                        : (int)hapStart + L - bMid - P.read_mate_pos[r];
+                }
+            }
+            const double lpOffR = T[T_MAPQ2 + 2 * mqi], lpOnR = T[T_MAPQ2 + 2 * mqi + 1];   // log(pOff), log(1-pOff)
+            const double lpOffH = T[TC_PINS + 1], lpOnH = T[TC_PINS + 2];
+            const double lIns0 = T[TC_PINS + 0], lIns1 = T[TC_IN];                          // logpIns for i = 0, 1 (:297)
+            const double pin0 = usePin ? P.lib_log95[P.read_lib[r]] : 0.0;
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int x = x0 + k;
                 const double o = ((mOwn[k] >> col) & 1u) ? eq : uq;
                 const double baseA = (a[k] + o) + be_a[k];              // alpha + obs + beta (:1098)
                 const double baseI = (in[k] + eq) + be_i[k];
-                vA[k] = baseA + ((x == 0) ? prOff0 : (x == RO ? roPrior : prOn0));    // read's mapping quality
-                vI[k] = baseI + ((x == 0) ? prOff1 : (x == RO ? roPrior : prOn1));
-                hA[k] = baseA + ((x == 0) ? hqOff0 : (x == RO ? roPrior : hqOn0));    // mapQual = 1-1e-10 (:1093)
-                hI[k] = baseI + ((x == 0) ? hqOff1 : (x == RO ? roPrior : hqOn1));
+                double pOn0 = prOn0, pOn1 = prOn1, qOn0 = hqOn0, qOn1 = hqOn1, pOf0 = prOff0, pOf1 = prOff1, qOf0 = hqOff0, qOf1 = hqOff1;
+                if (usePin) {
+                    int d = pinD0 + x;
+                    d = d < 0 ? -d : d;                                 // Library::getProb (Library.hpp:60-64)
+                    d = d >= pinMax ? pinMax - 1 : d;
+                    const double pin = (x >= 1 && x <= Hs) ? P.lib_logprob[pinBase + d] : 0.0;
+                    pOn0 = (pin + lpOnR) + lIns0; pOn1 = (pin + lpOnR) + lIns1;
+                    qOn0 = (pin + lpOnH) + lIns0; qOn1 = (pin + lpOnH) + lIns1;
+                    pOf0 = (lpOffR + lIns0) + pin0; pOf1 = (lpOffR + lIns1) + pin0;
+                    qOf0 = (lpOffH + lIns0) + pin0; qOf1 = (lpOffH + lIns1) + pin0;
+                }
+                vA[k] = baseA + ((x == 0) ? pOf0 : (x == RO ? roPrior : pOn0));    // read's mapping quality
+                vI[k] = baseI + ((x == 0) ? pOf1 : (x == RO ? roPrior : pOn1));
+                hA[k] = baseA + ((x == 0) ? qOf0 : (x == RO ? roPrior : qOn0));    // mapQual = 1-1e-10 (:1093)
+                hI[k] = baseI + ((x == 0) ? qOf1 : (x == RO ? roPrior : qOn1));
                 if (x >= 1 && x <= Hs) {                                   // (:1106-1107) plain max
                     on = vA[k] > on ? vA[k] : on;
                     on = vI[k] > on ? vI[k] : on;

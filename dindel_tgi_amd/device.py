@@ -20,6 +20,8 @@ def _to_dev(arr, device):
         a = a.view(np.int32)
     if a.size == 0:
         a = np.zeros(1, a.dtype)
+    if not a.flags.writeable:
+        a = a.copy()
     return torch.from_numpy(a).to(device, non_blocking=False)
 
 
@@ -55,6 +57,14 @@ class DeviceBatch:
         if lib.dd_build_symbol_lut(C.byref(hb), lut.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
             raise RuntimeError("dd_build_symbol_lut: " + capi.last_error())
         t["sym_lut"] = _to_dev(lut, self.device)
+        if pb.mate is not None and params.mapUnmappedReads:
+            lp = np.zeros(max(len(pb.mate["lib_prob"]), 1)); l95 = np.zeros(len(pb.mate["lib_p95"]))
+            if lib.dd_build_library_tables(C.byref(hb), lp.ctypes.data_as(capi.c_f64p), l95.ctypes.data_as(capi.c_f64p)) != 0:
+                raise RuntimeError("dd_build_library_tables: " + capi.last_error())
+            for k in ("read_mate_pos", "read_mate_len", "read_lib", "lib_off"):
+                t[k] = _to_dev(pb.mate[k], self.device)
+            t["lib_logprob"] = _to_dev(lp, self.device)
+            t["lib_log95"] = _to_dev(l95, self.device)
         if pb.hap_var_flank is not None and len(pb.hap_var_flank):
             t["hap_var_flank"] = _to_dev(pb.hap_var_flank, self.device)
         self.t = t

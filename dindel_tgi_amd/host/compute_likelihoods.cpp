@@ -1,5 +1,6 @@
 // compute_likelihoods.cpp — see compute_likelihoods.hpp.
 #include "compute_likelihoods.hpp"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -19,6 +20,32 @@ double Read::phredToProb(double phred)
     if (q < 1e-16) q = 1e-16;
     if (q > 1.0 - 1e-16) q = 1.0 - 1e-16;
     return q;
+}
+
+// reference Library.hpp:78-128
+void Library::calcProb(const std::vector<double> &counts)
+{
+    int max_isize = 2000;
+    double max_count = -1;
+    for (int s = 0; s < int(counts.size()); s++)
+        if (counts[size_t(s)] >= max_count) { max_count = double(int(counts[size_t(s)])); max_isize = s; }   // max_count is an int there
+    maxins = 25 * max_isize;
+    if (maxins > int(counts.size())) maxins = int(counts.size());
+    probs.assign(size_t(maxins), 0.0);
+    double z = 0.0;
+    for (int d = 0; d < maxins; d++) { probs[size_t(d)] = counts[size_t(d)]; z += probs[size_t(d)]; }
+    for (int d = 0; d < maxins; d++) {
+        probs[size_t(d)] /= z;
+        if (probs[size_t(d)] < 1e-10) probs[size_t(d)] = 1e-10;
+    }
+    std::vector<double> sorted(probs);
+    std::sort(sorted.begin(), sorted.end());
+    double sum = 0.0;
+    ninetyfifth_pct_prob = sorted.empty() ? 0.0 : sorted.back();
+    for (int x = int(sorted.size()) - 1; x > 0; x--) {
+        sum += sorted[size_t(x)];
+        if (sum > 0.95) { ninetyfifth_pct_prob = sorted[size_t(x)]; break; }
+    }
 }
 
 static dd_params to_abi(const ObservationModelParameters &o)
@@ -187,7 +214,11 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, hap_var_flank, read_seq_off(1, 0);
     std::vector<uint32_t> win_hap_start, read_start;
     std::string hap_seq, read_seq;
-    std::vector<uint8_t> read_qidx, read_mqidx, read_flags;
+    std::vector<uint8_t> read_qidx, read_mqidx, read_flags, read_lib;
+    std::vector<int32_t> read_mate_pos, read_mate_len, lib_off(1, 0);
+    std::vector<double> lib_prob, lib_p95;
+    std::map<const Library *, int> lib_index;
+    const bool with_mates = params.mapUnmappedReads && !faster;
     std::map<double, int> qmap, mqmap;
     std::vector<double> qtab, mqtab;
     for (int w = 0; w < W; w++) {
@@ -231,7 +262,27 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
             if (it->second > 255) throw std::string("more than 256 distinct mapping qualities in one batch");
             read_mqidx.push_back(uint8_t(it->second));
             read_start.push_back(uint32_t(R.posStat.first));      // uint32_t(read.posStat.first), ObservationModelFB.cpp:52
-            read_flags.push_back(R.isUnmapped() ? 1 : 0);
+            read_flags.push_back(uint8_t((R.isUnmapped() ? DD_READ_UNMAPPED : 0) | (R.isPaired() ? DD_READ_PAIRED : 0) |
+                                         (R.mateIsUnmapped() ? DD_READ_MATE_UNMAPPED : 0) | (R.mateIsReverse() ? DD_READ_MATE_REVERSE : 0) |
+                                         (R.mateSameTid ? DD_READ_MATE_SAME_TID : 0)));
+            if (with_mates) {
+                int li = 0;
+                if (R.isPaired()) {                      // the reference dereferences the library of paired reads only (:279-289)
+                    if (!R.library) throw std::string("Cannot find library: ");            // Read.hpp:176
+                    std::map<const Library *, int>::iterator lt = lib_index.find(R.library);
+                    if (lt == lib_index.end()) {
+                        if (lib_index.size() >= 256) throw std::string("more than 256 libraries in one batch");
+                        lt = lib_index.insert(std::make_pair(R.library, int(lib_index.size()))).first;
+                        lib_prob.insert(lib_prob.end(), R.library->table().begin(), R.library->table().end());
+                        lib_off.push_back(int32_t(lib_prob.size()));
+                        lib_p95.push_back(R.library->getNinetyFifthPctProb());
+                    }
+                    li = lt->second;
+                }
+                read_lib.push_back(uint8_t(li));
+                read_mate_pos.push_back(R.matePos);
+                read_mate_len.push_back(R.isPaired() ? R.mateLen : -1);
+            }
         }
         win_read_off.push_back(win_read_off.back() + int32_t(J.reads->size()));
     }
@@ -245,6 +296,11 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     B.read_seq_off = read_seq_off.data(); B.read_seq = read_seq.data(); B.read_qidx = read_qidx.data();
     B.read_mqidx = read_mqidx.data(); B.read_start = read_start.data(); B.read_flags = read_flags.data();
     B.n_qual = int(qtab.size()); B.qual_table = qtab.data(); B.n_mapq = int(mqtab.size()); B.mapq_table = mqtab.data();
+    if (with_mates) {
+        if (lib_p95.empty()) { lib_prob.push_back(1.0); lib_off.push_back(1); lib_p95.push_back(1.0); }   // no paired read: placeholder table
+        B.read_mate_pos = read_mate_pos.data(); B.read_mate_len = read_mate_len.data(); B.read_lib = read_lib.data();
+        B.n_libs = int(lib_p95.size()); B.lib_off = lib_off.data(); B.lib_prob = lib_prob.data(); B.lib_p95 = lib_p95.data();
+    }
 
     dd_sizes sz;
     if (dd_batch_sizes(&B, &sz) != DD_SUCCESS) throw std::string(dd_last_error());
@@ -266,7 +322,8 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     Rz.nMMLeft = nMMLeft.data(); Rz.nMMRight = nMMRight.data(); Rz.firstBase = firstBase.data(); Rz.lastBase = lastBase.data();
     Rz.onHap = onHapV.data();
     Rz.var_fcov = fcov.data(); Rz.var_covered = vcov.data();
-    const dd_params P = to_abi(params);
+    dd_params P = to_abi(params);
+    if (faster) P.mapUnmappedReads = 0;                 // ObservationModelS has no insert-size prior
     const std::chrono::steady_clock::time_point t_packed = std::chrono::steady_clock::now();
     if (sz.n_pairs > 0) {
         const int rc = faster ? dd_compute_likelihoods_faster(&P, &B, &Rz, device_) : dd_compute_likelihoods(&P, &B, &Rz, device_);

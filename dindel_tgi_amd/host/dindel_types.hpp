@@ -98,9 +98,28 @@ public:
     const char &operator[](size_t i) const { return seq[i]; }
 };
 
+// Insert-size distribution of a sequencing library — reference Library.hpp:37-140: probs[d] = normalised histogram
+// floored at 1e-10 over d < maxins = min(25 * mode, #bins); getProb clamps |x| to maxins-1; the "95th percentile
+// probability" is the smallest of the most probable bins that together hold > 95 % of the mass.
+class Library {
+public:
+    Library() : maxins(0), ninetyfifth_pct_prob(0.0) {}
+    explicit Library(const std::vector<double> &counts) { calcProb(counts); }
+    int getMaxInsertSize() const { return maxins; }
+    double getProb(int x) const { if (x < 0) x = -x; if (x >= maxins) x = maxins - 1; return probs[size_t(x)]; }
+    double getNinetyFifthPctProb() const { return ninetyfifth_pct_prob; }
+    const std::vector<double> &table() const { return probs; }
+private:
+    void calcProb(const std::vector<double> &counts);
+    int maxins;
+    double ninetyfifth_pct_prob;
+    std::vector<double> probs;
+};
+
 class Read {
 public:
-    Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false), reverse(false), mateReverse(false) {}
+    Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false), reverse(false), mateReverse(false),
+             paired(false), mateUnmapped(false), mateSameTid(false), matePos(-1), mateLen(-1), library(NULL) {}
     Haplotype seq;                       // read.seq.seq is the base string, as in the reference
     std::vector<double> qual;            // P(base correct) — reference Read.hpp:143-148
     double mapQual;                      // P(mapping correct) — reference Read.hpp:127-131
@@ -112,6 +131,13 @@ public:
     bool isUnmapped() const { return unmapped; }
     bool isReverse() const { return reverse; }
     bool mateIsReverse() const { return mateReverse; }
+    // inputs of the insert-size prior (mapUnmappedReads) — reference Read.hpp:162-204, 258, 426-434
+    bool paired, mateUnmapped, mateSameTid;   // BAM flags 0x1 / 0x8; bam->core.tid == bam->core.mtid
+    int32_t matePos, mateLen;            // bam->core.mpos; -1 until the mate has been seen (Read.hpp:163)
+    const Library *library;
+    bool isPaired() const { return paired; }
+    bool mateIsUnmapped() const { return mateUnmapped; }
+    const Library &getLibrary() const { return *library; }
     void setAllQual(double v) { qual.assign(seq.size(), v); }
     // Phred -> probability exactly as the BAM constructor does — reference Read.hpp:127-131, 143-148
     static double phredToProb(double phred);

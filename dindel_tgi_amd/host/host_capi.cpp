@@ -80,9 +80,12 @@ int ddh_rebuild_json(const char *hap, const char *read, const double *qual, cons
 
 // GPU: one window through LikelihoodEngine::computeLikelihoods.  haps / reads are '\n'-joined strings,
 // quals one double per read base (concatenated), mapq / start / unmapped per read.
+// mate: NULL, or 4 ints per read {bit0 paired | bit1 mateUnmapped | bit2 mateReverse | bit3 sameTid, matePos, mateLen, library index};
+// libraries as insert-size histograms (lib_counts concatenated, lib_sizes[n_libs]) -> dindel::Library; switches mapUnmappedReads on
 static int compute_window_json(bool faster, const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
                                const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
-                               int device, char *out, int cap)
+                               int device, char *out, int cap, const int *mate = NULL, const double *lib_counts = NULL,
+                               const int *lib_sizes = NULL, int n_libs = 0)
 {
     try {
         std::vector<Haplotype> haps;
@@ -103,7 +106,20 @@ static int compute_window_json(bool faster, const char *haps_nl, const char *rea
             reads.push_back(R);
             ri++;
         }
-        LikelihoodEngine eng(make_params(pd, pi), device);
+        std::vector<Library> libs;
+        if (mate) {
+            size_t o = 0;
+            for (int i = 0; i < n_libs; i++) { libs.push_back(Library(std::vector<double>(lib_counts + o, lib_counts + o + lib_sizes[i]))); o += size_t(lib_sizes[i]); }
+            for (size_t r = 0; r < reads.size(); r++) {
+                const int *m = mate + 4 * r;
+                reads[r].paired = (m[0] & 1) != 0; reads[r].mateUnmapped = (m[0] & 2) != 0; reads[r].mateReverse = (m[0] & 4) != 0;
+                reads[r].mateSameTid = (m[0] & 8) != 0; reads[r].matePos = m[1]; reads[r].mateLen = m[2];
+                reads[r].library = (m[3] >= 0 && m[3] < n_libs) ? &libs[size_t(m[3])] : NULL;
+            }
+        }
+        ObservationModelParameters prm = make_params(pd, pi);
+        prm.mapUnmappedReads = mate != NULL;
+        LikelihoodEngine eng(prm, device);
         eng.setThrowOnPositiveLikelihood(true);
         std::vector<std::vector<MLAlignment> > liks;
         std::vector<int> onHap;
@@ -130,6 +146,15 @@ int ddh_compute_window_json(const char *haps_nl, const char *reads_nl, const dou
                             int device, char *out, int cap)
 {
     return compute_window_json(false, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap);
+}
+
+// computeLikelihoods with the insert-size prior (mapUnmappedReads; the reference's --libFile run)
+int ddh_compute_window_mates_json(const char *haps_nl, const char *reads_nl, const double *quals, const double *mapq,
+                                  const double *pos_first, const int *unmapped, unsigned leftPos, const double *pd, const int *pi,
+                                  int device, const int *mate, const double *lib_counts, const int *lib_sizes, int n_libs, char *out, int cap)
+{
+    return compute_window_json(false, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap,
+                               mate, lib_counts, lib_sizes, n_libs);
 }
 
 // the same through LikelihoodEngine::computeLikelihoodsFaster (--faster model)

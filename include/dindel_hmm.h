@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 6
+#define DD_ABI_VERSION 7
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -75,7 +75,8 @@ typedef struct dd_params {
     int32_t padCover;                /* "flankRefSeq"                                                */
     int32_t bMid;                    /* -1 = compute from overlap (ObservationModelFB.cpp:96)        */
     int32_t forceReadOnHaplotype;    /* ObservationModelFB.cpp:307-316                               */
-    int32_t mapUnmappedReads;        /* must be 0 (needs Library insert-size pmf; out of scope)      */
+    int32_t mapUnmappedReads;        /* 1: add the library insert-size prior of paired reads at the join (ObservationModelFB.cpp:279-292;
+                                        the CLI sets it with --libFile, DInDel.cpp:4268-4272); needs the mate / library arrays of dd_batch */
     int32_t maxMismatch;             /* "flankMaxMismatch": used only by the filterHaplotypes coverage flags */
     double  capMapQualFast;          /* phred cap on the mapping quality in the --faster model (Faster.cpp:117); 40 / CLI 45 */
 } dd_params;
@@ -114,7 +115,7 @@ typedef struct dd_batch {
     const uint8_t *read_qidx;      /* per base: index into qual_table                                */
     const uint8_t *read_mqidx;     /* [n_reads]     index into mapq_table                            */
     const uint32_t*read_start;     /* [n_reads]     uint32_t(read.posStat.first)                     */
-    const uint8_t *read_flags;     /* [n_reads]     bit0 = read.isUnmapped() (BAM flag 0x4)          */
+    const uint8_t *read_flags;     /* [n_reads]     DD_READ_* bits; bit0 = read.isUnmapped() (BAM flag 0x4) */
 
     int32_t        n_qual;  const double *qual_table;  /* P(base correct), Read.hpp:143-148          */
     int32_t        n_mapq;  const double *mapq_table;  /* read.mapQual,    Read.hpp:127-131          */
@@ -122,7 +123,24 @@ typedef struct dd_batch {
     const int32_t *hap_var_flank;  /* optional (NULL = none), per variant of hap_var, 3 ints:
                                       {getLeftFlankRead(), getRightFlankRead(), kind}, kind 1 = DEL, 2 = INS,
                                       0 = neither (SNP entries): inputs of filterHaplotypes, DInDel.cpp:1973-1976 */
+
+    /* Only read when dd_params.mapUnmappedReads != 0 (NULL otherwise): what computeBMidPrior takes from the mate and the
+     * read's library (ObservationModelFB.cpp:279-292, Read.hpp:162-204,426, Library.hpp:60-66). */
+    const int32_t *read_mate_pos;  /* [n_reads]     read.matePos                                     */
+    const int32_t *read_mate_len;  /* [n_reads]     read.mateLen, -1 = unknown (no prior for that read) */
+    const uint8_t *read_lib;       /* [n_reads]     index of read.getLibrary() in the tables below   */
+    int32_t        n_libs;
+    const int32_t *lib_off;        /* [n_libs+1]    into lib_prob; a library has maxins = lib_off[i+1]-lib_off[i] >= 1 entries */
+    const double  *lib_prob;       /* Library::getProb(x) for x = 0..maxins-1 (normalised, floored at 1e-10) */
+    const double  *lib_p95;        /* [n_libs]      Library::getNinetyFifthPctProb()                 */
 } dd_batch;
+
+/* read_flags bits (BAM flag bits the path looks at: Read.hpp:201-204, ObservationModelFB.cpp:56,279-281) */
+#define DD_READ_UNMAPPED       1   /* read.isUnmapped()                                    */
+#define DD_READ_PAIRED         2   /* read.isPaired()                                      */
+#define DD_READ_MATE_UNMAPPED  4   /* read.mateIsUnmapped()                                */
+#define DD_READ_MATE_REVERSE   8   /* read.mateIsReverse()                                 */
+#define DD_READ_MATE_SAME_TID 16   /* bam->core.tid == bam->core.mtid                      */
 
 /* Per (window,hap,read) pair, in pair order.  Any output pointer may be NULL (then not written),
  * except ll and status. Mirrors MLAlignment (MLAlignment.hpp:28-76). */
@@ -172,7 +190,7 @@ void dd_release_cache(void);
 /* Table block built on the host with libm (emission logs per quality, bMid priors per mapping
  * quality, homopolymer indel-error logs, transition constants).  Returns number of doubles written
  * (<= DD_TABLE_DOUBLES); `out` is host memory that the caller copies to the device. */
-#define DD_TABLE_DOUBLES (32 + 4*DD_MAX_QUAL_TABLE + 4*DD_MAX_QUAL_TABLE + 2*DD_HP_TABLE + 2*DD_MAX_QUAL_TABLE + 64)
+#define DD_TABLE_DOUBLES (32 + 4*DD_MAX_QUAL_TABLE + 4*DD_MAX_QUAL_TABLE + 2*DD_HP_TABLE + 2*DD_MAX_QUAL_TABLE + 2*DD_MAX_QUAL_TABLE + 64)
 int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
                     const double *mapq_table, int n_mapq, double *out);
 
@@ -181,6 +199,10 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
  * the main kernel uses (A,C,G,T -> 0..3, N -> 4, other bytes present in a haplotype of the batch -> 5..30, the rest -> 31);
  * out[256].  More than 26 distinct non-ACGTN haplotype bytes in one batch -> DD_ERR_UNSUPPORTED. */
 int dd_build_symbol_lut(const dd_batch *b, uint8_t *out);
+
+/* log(Library::getProb(x)) for every entry of dd_batch.lib_prob (logprob_out[lib_off[n_libs]]) and
+ * log(getNinetyFifthPctProb()) per library (log95_out[n_libs]), taken with libm on the host. */
+int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log95_out);
 
 /* Host-side derived index arrays the kernels need, sized by the caller:
  * hap_window[n_haps], win_pair_off[n_windows+1], win_hpos_off[n_windows+1], win_varcov_off[n_windows+1] */
@@ -199,6 +221,10 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
     int32_t n_qual, n_mapq;
     const int32_t *hap_var_flank;   /* optional, see dd_batch */
     const uint8_t *sym_lut;         /* optional: 256 bytes from dd_build_symbol_lut; NULL = haplotypes hold A,C,G,T,N only */
+    /* mapUnmappedReads only (NULL otherwise): device copies of dd_batch's mate arrays and the log tables of
+     * dd_build_library_tables */
+    const int32_t *read_mate_pos, *read_mate_len; const uint8_t *read_lib;
+    const int32_t *lib_off; const double *lib_logprob, *lib_log95;
 } dd_device_batch;
 
 /* bytes of device scratch dd_launch_device needs for this shape (0 if none) */

@@ -151,26 +151,56 @@ static void pass_two_dec(const hmm_t *m, double *beta_l, const double *beta_l_1,
         update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[x] + beta_l_1[x] + m->logpNoInsgIns, x);
 }
 
-/* ObservationModelFB::computeBMidPrior — ObservationModelFB.cpp:268-305 (pinsert == 0: mapUnmappedReads off) */
-static void bmid_prior(const hmm_t *m, const dd_params *P, double *prior, double mapQual)
+/* ObservationModelFB::computeBMidPrior — ObservationModelFB.cpp:268-305.  mate == NULL: mapUnmappedReads off or the read
+ * is not paired (pinsert stays 0).  Library::getProb — Library.hpp:60-64. */
+static double lib_get_prob(const struct ddo_mate *mt, int x)
+{
+    if (x < 0) x = -x;
+    if (x >= mt->maxins) x = mt->maxins - 1;
+    return mt->lib_prob[x];
+}
+
+static void bmid_prior(const hmm_t *m, const dd_params *P, double *prior, double mapQual, const ddo_mate *mt, int hapStart, int readSize)
 {
     double mq = 1.0 - mapQual;
     int x;
     size_t i;
     if (-10.0 * log10(mq) > P->mapQualThreshold) mq = pow(10.0, -P->mapQualThreshold / 10.0);
     double pOffFirst = mq;
-    const double pinsert = 0.0;
+    double *pinsert = (double *)calloc((size_t)m->numS, sizeof(double));
+    if (P->mapUnmappedReads && mt && mt->paired) {                                           /* :279 */
+        if (!mt->mate_unmapped && mt->mate_len != -1 && mt->same_tid) {                      /* :283 */
+            if (mt->mate_reverse) {
+                for (x = 1; x < m->hapSize + 1; x++) pinsert[x] = log(lib_get_prob(mt, abs(hapStart + x - m->bMid - (int)(mt->mate_pos + mt->mate_len))));
+            } else {
+                for (x = 1; x < m->hapSize + 1; x++) pinsert[x] = log(lib_get_prob(mt, abs(hapStart + x + readSize - m->bMid - (int)(mt->mate_pos))));
+            }
+            pinsert[0] = log(mt->p95);
+        }
+    }
     for (i = 0; i < 2; i++) {
         double logpIns = (i == 1) ? (m->logpInsgNoIns) : log(1.0 - exp(m->logpInsgNoIns));
-        prior[i * m->numS + 0] = log(pOffFirst) + logpIns + pinsert;
+        prior[i * m->numS + 0] = log(pOffFirst) + logpIns + pinsert[0];
         prior[i * m->numS + m->ROState] = -100.0;
-        for (x = 1; x < m->hapSize + 1; x++) prior[i * m->numS + x] = pinsert + log((1.0 - pOffFirst)) + logpIns;
+        for (x = 1; x < m->hapSize + 1; x++) prior[i * m->numS + x] = pinsert[x] + log((1.0 - pOffFirst)) + logpIns;
     }
+    free(pinsert);
 }
+
+int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                  const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos);
 
 int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, int L,
              double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
              const dd_params *P, ddo_out *out, int *hpos)
+{
+    return ddo_pair_mate(hap, Hs, readseq, qual, L, mapQual, readStartU32, hapStart, unmapped, P, NULL, out, hpos);
+}
+
+int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                  const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos)
 {
     hmm_t M;
     hmm_t *m = &M;
@@ -304,8 +334,8 @@ int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, i
         double llHMQ = -HUGE_VAL;
         double *priorRMQ = (double *)calloc((size_t)T, sizeof(double));
         double *priorHMQ = (double *)calloc((size_t)T, sizeof(double));
-        bmid_prior(m, P, priorRMQ, mapQual);
-        bmid_prior(m, P, priorHMQ, 1.0 - 1e-10);
+        bmid_prior(m, P, priorRMQ, mapQual, mate, (int)hapStart, L);
+        bmid_prior(m, P, priorHMQ, 1.0 - 1e-10, mate, (int)hapStart, L);
         for (x = 0, y = 0; x < T; x++, y++) {
             double v = alpha_l[y] + obs_l[y] + beta_l[y] + priorRMQ[y];
             if (v > logLikelihood + EPS) { logLikelihood = v; mapStateRMQ = x; }
@@ -456,9 +486,20 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
                 ddo_out o;
                 int64_t p = pair_off[w] + (int64_t)(h - h0) * Rn + (r - r0);
                 for (i = 0; i < L; i++) q[i] = B->qual_table[B->read_qidx[so + i]];
-                if (model == 0)
-                    ddo_pair(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
-                             B->win_hap_start[w], B->read_flags[r] & 1, P, &o, hp);
+                if (model == 0) {
+                    ddo_mate mt, *pm = NULL;
+                    if (P->mapUnmappedReads && B->read_mate_pos) {
+                        int fl = B->read_flags[r], lib = B->read_lib[r];
+                        mt.paired = (fl & DD_READ_PAIRED) != 0; mt.mate_unmapped = (fl & DD_READ_MATE_UNMAPPED) != 0;
+                        mt.mate_reverse = (fl & DD_READ_MATE_REVERSE) != 0; mt.same_tid = (fl & DD_READ_MATE_SAME_TID) != 0;
+                        mt.mate_pos = B->read_mate_pos[r]; mt.mate_len = B->read_mate_len[r];
+                        mt.lib_prob = B->lib_prob + B->lib_off[lib]; mt.maxins = B->lib_off[lib + 1] - B->lib_off[lib];
+                        mt.p95 = B->lib_p95[lib];
+                        pm = &mt;
+                    }
+                    ddo_pair_mate(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
+                                  B->win_hap_start[w], B->read_flags[r] & 1, P, pm, &o, hp);
+                }
                 else {
                     ddo_pair_fast(hs, Hs, B->read_seq + so, q, L, B->mapq_table[B->read_mqidx[r]], B->read_start[r],
                                   B->win_hap_start[w], P, &o, hp);

@@ -17,10 +17,22 @@ typedef struct ddo_out {
     int32_t n_snp, snp_pos[DDO_MAX_VAR], snp_rpos[DDO_MAX_VAR];
 } ddo_out;
 
+/* what computeBMidPrior takes from the mate and the library when mapUnmappedReads is on (ObservationModelFB.cpp:279-292) */
+typedef struct ddo_mate {
+    int paired, mate_unmapped, mate_reverse, same_tid;   /* read.isPaired(), mateIsUnmapped(), mateIsReverse(), tid == mtid */
+    int32_t mate_pos, mate_len;                          /* read.matePos, read.mateLen (-1 unknown) */
+    const double *lib_prob; int maxins; double p95;      /* Library::probs, maxins, ninetyfifth_pct_prob */
+} ddo_mate;
+
 /* one (haplotype, read) pair: ObservationModelFBMaxErr(hap, read, hapStart, params).calcLikelihood() */
 int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, int L,
              double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
              const dd_params *P, ddo_out *out, int *hpos /* [L] */);
+
+/* the same with the insert-size prior inputs (mate == NULL: none) */
+int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                  double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                  const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos);
 
 /* a batch in the product's flat layout; windows [first_window, first_window+n_win) (n_win<0: all) */
 int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win);

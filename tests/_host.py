@@ -82,3 +82,22 @@ def filter_window(haps, hap_vars, reads, quals, mapq, pos_first, rflags, left_po
                                    (1 if do_filter else 0) | (2 if faster else 0), device, out, len(out))
     assert n > 0, n
     return json.loads(out.value.decode())
+
+
+def compute_window_mates(haps, reads, quals, mapq, pos_first, unmapped, left_pos, params, mate, lib_counts, device=0):
+    """computeLikelihoods with mapUnmappedReads: mate = per read (flags, matePos, mateLen, lib); lib_counts = list of histograms."""
+    lib = load()
+    q = np.ascontiguousarray(np.concatenate([np.broadcast_to(np.asarray(x, np.float64), (len(r),)) for x, r in zip(quals, reads)]))
+    mq = np.asarray(mapq, np.float64); pf = np.asarray(pos_first, np.float64); um = np.asarray(unmapped, np.int32)
+    mt = np.ascontiguousarray(np.asarray(mate, np.int32).reshape(-1))
+    lc = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64) for c in lib_counts]))
+    ls = np.asarray([len(c) for c in lib_counts], np.int32)
+    pd, pi = _params(params)
+    out = C.create_string_buffer(1 << 24)
+    n = lib.ddh_compute_window_mates_json("\n".join(haps).encode(), "\n".join(reads).encode(), q.ctypes.data_as(capi.c_f64p),
+                                          mq.ctypes.data_as(capi.c_f64p), pf.ctypes.data_as(capi.c_f64p),
+                                          um.ctypes.data_as(capi.c_i32p), C.c_uint(left_pos & 0xFFFFFFFF), pd, pi, device,
+                                          mt.ctypes.data_as(capi.c_i32p), lc.ctypes.data_as(capi.c_f64p),
+                                          ls.ctypes.data_as(capi.c_i32p), len(lib_counts), out, len(out))
+    assert n > 0, n
+    return json.loads(out.value.decode())

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(capi.EXPORTS), (names, capi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.dd_abi_version() == 6
+    assert lib.dd_abi_version() == 7
     assert lib.dd_kernel_name().decode() == "dd_hmm_kernel"
 
 
@@ -111,8 +111,11 @@ def test_no_cpu_fallback_and_validation(lib):
     bb = bad.ctypes_batch()
     assert lib.dd_compute_likelihoods(C.byref(p), C.byref(bb), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
     assert "26 distinct" in capi.last_error()
-    p2 = capi.params_cli_defaults(); p2.mapUnmappedReads = 1
-    assert lib.dd_compute_likelihoods(C.byref(p2), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    p2 = capi.params_cli_defaults(); p2.mapUnmappedReads = 1                 # needs the mate / library arrays
+    assert lib.dd_compute_likelihoods(C.byref(p2), C.byref(b), C.byref(res), 0) == capi.DD_ERR_INVALID
+    assert "mapUnmappedReads" in capi.last_error()
+    p4 = capi.params_cli_defaults(); p4.forceReadOnHaplotype = 1
+    assert lib.dd_compute_likelihoods(C.byref(p4), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
     p3 = capi.params_cli_defaults(); p3.maxLengthDel = 12
     assert lib.dd_compute_likelihoods(C.byref(p3), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
     res2 = capi.dd_result()
