@@ -112,6 +112,24 @@ def test_insert_prior_gpu_parity(lib, seed):
 
 
 @pytest.mark.gpu
+def test_faster_model_ignores_the_insert_prior(lib):
+    """ObservationModelS has no insert-size prior (Faster.cpp never reads the library): same results with the option on."""
+    from tests.test_gpu_faster import run_faster
+    rng = np.random.default_rng(31)
+    libs = [library(rng, 300, 120)]
+    pb = pack(windows_with_mates(rng, 8, libs), libraries=libs)
+    p = capi.params_cli_defaults()
+    off = run_faster(lib, p, pb)
+    p.mapUnmappedReads = 1
+    on = run_faster(lib, p, pb)
+    assert np.array_equal(on["ll"][:pb.n_pairs], off["ll"][:pb.n_pairs])
+    assert np.array_equal(on["hpos"][:pb.hpos_len], off["hpos"][:pb.hpos_len])
+    bare = pack(windows_with_mates(np.random.default_rng(31), 8, libs))          # no mate arrays at all: still fine for --faster
+    assert bare.mate is None
+    run_faster(lib, p, bare)
+
+
+@pytest.mark.gpu
 def test_insert_prior_device_pointer_path(lib):
     import torch
     from dindel_tgi_amd.device import DeviceBatch

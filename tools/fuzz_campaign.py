@@ -45,7 +45,20 @@ while time.time() < t_end:
         max_hap = int(rng.choice([40, 62, 126, 190, 254, 400, 755]))   # make_windows adds up to 7 inserted bases
         ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1,
                           with_vars=bool(rng.random() < 0.6))
-        pb = pack(ws)
+        libs = None
+        if rng.random() < 0.5:                                          # insert-size prior inputs (mapUnmappedReads)
+            from tests.test_insert_prior import library
+            libs = [library(rng, int(rng.integers(1, 900)), int(rng.integers(1, 400))) for _ in range(int(rng.integers(1, 4)))]
+            p.mapUnmappedReads = int(rng.random() < 0.85)
+            for w in ws:
+                for r in w.reads:
+                    r.paired = bool(rng.random() < 0.8); r.mate_unmapped = bool(rng.random() < 0.1)
+                    r.mate_reverse = bool(rng.random() < 0.5); r.mate_same_tid = bool(rng.random() < 0.9)
+                    mp = int(rng.choice([r.start + int(rng.integers(-500, 500)), -1, 0, 2 ** 31 - 5]))
+                    r.mate_pos = (mp + 2 ** 31) % 2 ** 32 - 2 ** 31          # int32, as bam->core.mpos
+                    r.mate_len = int(rng.choice([-1, 0, 36, 100]))
+                    r.lib = int(rng.integers(0, len(libs)))
+        pb = pack(ws, libraries=libs)
     elif kind == 1:
         pb = synth.generate(int(rng.integers(1, 8)), H=int(rng.integers(1, 17)), R=int(rng.integers(1, 300)),
                             L=int(rng.integers(8, 260)), hap_len=int(rng.integers(24, 400)), seed=seed,
