@@ -230,7 +230,7 @@ def main():
                 assert rc == 0, capi.last_error()
             out["host_api"] = {"seconds": dt, "cells_per_s": cells / dt, "windows_per_s": args.windows / dt,
                                "note": "dd_compute_likelihoods with host pointers: H2D of the batch, kernels, D2H of every output"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would idle in the collective teardown)
             out["cpu_baseline"] = cpu_baseline(pb, params, faster=args.faster)
         if args.faster:
             out["metric"] = "read-haplotype cells/s, --faster model (ObservationModelS)"
