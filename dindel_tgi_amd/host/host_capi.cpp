@@ -6,6 +6,7 @@
 #include <string>
 #include "compute_likelihoods.hpp"
 #include "genotype.hpp"
+#include "cigar.hpp"
 
 using namespace dindel;
 
@@ -163,6 +164,26 @@ int ddh_compute_window_faster_json(const char *haps_nl, const char *reads_nl, co
                                    int device, char *out, int cap)
 {
     return compute_window_json(true, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap);
+}
+
+// N4: getCIGAR.  out_ops receives (op, len) pairs; returns the number of operations, or -(1+k) for the k-th throw string of
+// {"Haplotype has not been aligned!", "Read is not properly aligned!", "Error(1)!", "Error(2)!", "Error(3)!", "Error(4)!", "How is this possible? (1)"}
+int ddh_get_cigar(const int *hap_ref_pos, int hap_size, const short *hpos, int read_size, int ref_seq_start, int *out_ops, int cap, int *ref_pos)
+{
+    static const char *msgs[] = {"Haplotype has not been aligned!", "Read is not properly aligned!", "Error(1)!", "Error(2)!", "Error(3)!",
+                                 "Error(4)!", "How is this possible? (1)"};
+    try {
+        MLAlignment ml;
+        ml.hpos.assign(hpos, hpos + read_size);
+        CIGAR c = getCIGAR(std::vector<int>(hap_ref_pos, hap_ref_pos + hap_size), size_t(hap_size), ml, size_t(read_size), ref_seq_start);
+        if (int(c.size()) * 2 > cap) return -100;
+        for (size_t i = 0; i < c.size(); i++) { out_ops[2 * i] = c[i].first; out_ops[2 * i + 1] = c[i].second; }
+        *ref_pos = c.refPos;
+        return int(c.size());
+    } catch (std::string &e) {
+        for (int k = 0; k < 7; k++) if (e == msgs[k]) return -(1 + k);
+        return -99;
+    }
 }
 
 // N1 host step: returns {max_indel_pair, max_noindel_pair, max_ll_indel, max_ll_noindel, qual} or -1 on the

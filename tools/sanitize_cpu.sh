@@ -6,9 +6,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 gcc -O1 -g -fPIC -std=c99 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared \
     -o /tmp/libdd_oracle_asan.so "$ROOT/oracle/dd_oracle.c" -lm
 g++ -O1 -g -fPIC -std=c++11 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o /tmp/libdindel_host_asan.so \
-    "$ROOT"/dindel_tgi_amd/host/{compute_likelihoods,genotype,host_capi}.cpp -L"$ROOT/dindel_tgi_amd/csrc" -ldindel_hmm \
+    "$ROOT"/dindel_tgi_amd/host/{compute_likelihoods,genotype,cigar,host_capi}.cpp -L"$ROOT/dindel_tgi_amd/csrc" -ldindel_hmm \
     -Wl,-rpath,"$ROOT/dindel_tgi_amd/csrc"
 cd "$ROOT"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 DD_ORACLE_LIB=/tmp/libdd_oracle_asan.so \
     DD_HOST_LIB=/tmp/libdindel_host_asan.so python -m pytest tests/test_oracle_kat.py tests/test_oracle_fast_cpu.py tests/test_host_adapter_cpu.py \
-    tests/test_genotype_n1.py -q -m "not gpu" -p no:cacheprovider
+    tests/test_genotype_n1.py tests/test_cigar_cpu.py -q -m "not gpu" -p no:cacheprovider
