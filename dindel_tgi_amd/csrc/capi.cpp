@@ -501,8 +501,8 @@ struct LenClass {
     bool run_onhap = true;
 };
 
-// 0: ObservationModelFBMaxErr (computeLikelihoods), 1: ObservationModelS (computeLikelihoodsFaster); set by the entry points
-static thread_local int g_model = 0;
+// which per-pair model an entry point runs
+enum Model { MODEL_FBMAXERR = 0 /* ObservationModelFBMaxErr, computeLikelihoods */, MODEL_S = 1 /* ObservationModelS, computeLikelihoodsFaster */ };
 
 // --faster model LDS: block-shared haplotype index + per-pair areas (layout in faster_kernel.hip's header)
 static size_t lds_layout_fast(int max_hap_len, int max_read_len, int n_qual, int &waves, int &groups, ddk::KernelArgs &A)
@@ -583,7 +583,7 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
     return DD_SUCCESS;
 }
 
-static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes,
+static int launch_range(Model model, const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes,
                         void *stream, int hap_begin, int hap_end, int read_begin, int read_end, const LenClass *lc = nullptr)
 {
     int rc = check_params(p);
@@ -602,7 +602,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
     A.read_start = b->read_start; A.read_flags = b->read_flags;
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
     A.win_varcov_off = b->win_varcov_off; A.tables = b->tables; A.sym_lut = b->sym_lut;
-    if (p->mapUnmappedReads && g_model == 0) {              // the --faster model has no insert-size prior
+    if (p->mapUnmappedReads && model == MODEL_FBMAXERR) {   // the --faster model has no insert-size prior
         if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib || !b->lib_off || !b->lib_logprob || !b->lib_log95)
             return fail(DD_ERR_INVALID, "mapUnmappedReads needs the mate arrays and the library log tables");
         A.read_mate_pos = b->read_mate_pos; A.read_mate_len = b->read_mate_len; A.read_lib = b->read_lib;
@@ -614,7 +614,7 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
 #endif
     A.always_ro = getenv("DD_ALWAYS_RO") ? 1 : 0;
     A.D = D; A.maxLengthDel = p->maxLengthDel; A.padCover = p->padCover; A.bMid = p->bMid; A.maxMismatch = p->maxMismatch;
-    if (g_model == 1) {
+    if (model == MODEL_S) {
         if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
         return launch_fast(p, b, A, stream, hap_begin, hap_end, read_begin, read_end, r->onHap && r->offHapHMQ);
     }
@@ -665,16 +665,12 @@ static int launch_range(const dd_params *p, const dd_device_batch *b, const dd_r
 
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
-    g_model = 0;
-    return launch_range(p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
+    return launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
 }
 
 int dd_launch_device_faster(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *stream)
 {
-    g_model = 1;
-    const int rc = launch_range(p, b, r, nullptr, 0, stream, 0, -1, 0, 0);
-    g_model = 0;
-    return rc;
+    return launch_range(MODEL_S, p, b, r, nullptr, 0, stream, 0, -1, 0, 0);
 }
 
 int dd_pair_sum_offsets(const dd_batch *b, int64_t *win_hh_off)
@@ -808,23 +804,19 @@ int dd_pair_sums(const dd_batch *b, const double *ll_host, double *out_host, int
     return DD_SUCCESS;
 }
 
-static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_batch *b, dd_result *r, int device);
 
 int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
-    g_model = 0;
-    return compute_likelihoods_impl(p, b, r, device);
+    return compute_likelihoods_impl(MODEL_FBMAXERR, p, b, r, device);
 }
 
 int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
-    g_model = 1;
-    const int rc = compute_likelihoods_impl(p, b, r, device);
-    g_model = 0;
-    return rc;
+    return compute_likelihoods_impl(MODEL_S, p, b, r, device);
 }
 
-static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_result *r, int device)
+static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -844,7 +836,7 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
     uint8_t sym_lut[256];
     if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
     std::vector<double> lib_logprob, lib_log95;
-    if (p->mapUnmappedReads && g_model == 0) {
+    if (p->mapUnmappedReads && model == MODEL_FBMAXERR) {
         if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib)
             return fail(DD_ERR_INVALID, "mapUnmappedReads needs read_mate_pos, read_mate_len and read_lib");
         if (b->n_libs < 1 || !b->lib_off) return fail(DD_ERR_INVALID, "mapUnmappedReads needs the library tables");
@@ -923,12 +915,12 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
     db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
     db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
     db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
-    size_t ws_bytes = g_model == 1 ? 0 : dd_workspace_bytes(p, &db);
+    size_t ws_bytes = model == MODEL_S ? 0 : dd_workspace_bytes(p, &db);
     int n_classes = 0;
     for (auto &hc : hcls) {
         if (hc.haps.empty()) continue;
         n_classes++;
-        if (g_model == 1) continue;
+        if (model == MODEL_S) continue;
         for (auto &rcl : rcls) {
             dd_device_batch tmp = db;
             tmp.max_hap_len = hc.max_hap; tmp.max_read_len = rcl.max_len;
@@ -936,7 +928,7 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
             if (w > ws_bytes) ws_bytes = w;
         }
     }
-    const bool single_class = g_model == 1 || (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
+    const bool single_class = model == MODEL_S || (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
 
     // ---- device arena (cached per host thread) ----
     const size_t np = (size_t)sz.n_pairs;
@@ -1033,7 +1025,7 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
         const int w0 = cw[c], w1 = cw[c + 1];
         const int g0 = b->win_hap_off[w0], g1 = b->win_hap_off[w1], q0 = b->win_read_off[w0], q1 = b->win_read_off[w1];
         if (single_class) {
-            rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1);
+            rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1);
             if (rc) return rc;
         } else {
             // every (K class, length class) of this window block, then onHap once
@@ -1049,7 +1041,7 @@ static int compute_likelihoods_impl(const dd_params *p, const dd_batch *b, dd_re
                 for (auto &rcl : rcls) {
                     lc.min_read_len = rcl.lo; lc.max_read_len = rcl.max_len;
                     lc.run_onhap = (++launched == total);
-                    rc = launch_range(p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
+                    rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
                     if (rc) return rc;
                 }
             }
