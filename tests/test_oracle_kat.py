@@ -81,3 +81,21 @@ def test_faster_model_kat():
         assert o.offHap == 0 and o.offHapHMQ == 0          # always false in this model (Faster.cpp:491, :529)
         n += 1
     assert n == 3
+
+
+def test_oracle_regression_vectors():
+    """tests/golden/oracle_regression.json (made by make_oracle_regression.py): the restatement's own outputs, bit for bit."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_regression.json")))
+    for c in d["cases"]:
+        p = capi.params_cli_defaults() if c["defaults"] == "cli" else capi.params_struct_defaults()
+        p.maxLengthDel = c["maxLengthDel"]
+        o, hpos = _oracle.pair(c["hap"], c["read"], c["qual"], c["mapQual"], c["start"], c["hapStart"], p, unmapped=c["unmapped"])
+        assert (o.status, o.offHap, o.offHapHMQ, o.numIndels) == (c["status"], c["offHap"], c["offHapHMQ"], c["numIndels"])
+        assert (o.ll.hex(), o.llOn.hex(), o.llOff.hex()) == (c["ll"], c["llOn"], c["llOff"])
+        assert hpos == c["hpos"]
+        f, fh = _oracle.pair_fast(c["hap"], c["read"], c["qual"], c["mapQual"], c["start"], c["hapStart"], p)
+        assert f.status == c["fast_status"]
+        if f.status == 0:
+            assert f.ll.hex() == c["fast_ll"] and fh == c["fast_hpos"]
