@@ -62,6 +62,8 @@ typedef struct {
     double *obs, *alpha, *beta;            /* [readSize][2*numS] */
     int *btf, *btb;                        /* [readSize][2*numS] */
     int *mapState;                         /* [readSize] */
+    int plain_fbmax;                       /* 1: ObservationModelFBMax (sibling model, KAT cross-check only) */
+    double logPTrans[DD_MAX_LENGTH_DEL + 3];
 } hmm_t;
 
 /* ObservationModelFBMaxErr::passMessageTwoInc — ObservationModelFB.cpp:1715-1773 */
@@ -151,6 +153,73 @@ static void pass_two_dec(const hmm_t *m, double *beta_l, const double *beta_l_1,
         update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[x] + beta_l_1[x] + m->logpNoInsgIns, x);
 }
 
+/* ---- ObservationModelFBMax (the class FBMaxErr derives from; NOT on the production path) --------------------------------
+ * Only here because SURVEY §8(c) also lists this model's log-likelihood for S1 / S2: three more reference numbers that pin
+ * everything the two models share (Init/bMid, emissions, priors, join, updateMax, traceback).
+ * passMessageTwoInc — ObservationModelFB.cpp:892-948; passMessageTwoDec — :1003-1055; transitions — :183-218. */
+static void fbmax_two_inc(const hmm_t *m, double *beta_l, const double *beta_l_1, const double *obs_l_1, int *bt_l)
+{
+    const int hapSize = m->hapSize, numS = m->numS, ROState = m->ROState, numT = m->numT;
+    int x, y;
+    beta_l[0] = -HUGE_VAL;
+    update_max(&beta_l[0], &bt_l[0], obs_l_1[0] + beta_l_1[0] + m->logpLOgLO + m->logpNoInsgNoIns, 0);
+    update_max(&beta_l[0], &bt_l[0], obs_l_1[1] + beta_l_1[1] + m->logpFirstgLO + m->logpNoInsgNoIns, 1);
+    for (x = 1; x <= hapSize; x++) {
+        beta_l[x] = -HUGE_VAL;
+        for (y = 1; y < numT; y++) {
+            int newx = x + y;
+            if (newx > hapSize) newx = ROState;
+            update_max(&beta_l[x], &bt_l[x], m->logPTrans[y] + m->logpNoInsgNoIns + beta_l_1[newx] + obs_l_1[newx], newx);
+        }
+    }
+    beta_l[ROState] = -HUGE_VAL;
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[ROState] + beta_l_1[ROState] + m->logpNoInsgNoIns, ROState);
+    for (x = 0; x <= hapSize + 1; x++)
+        update_max(&beta_l[x], &bt_l[x], obs_l_1[numS + x] + beta_l_1[numS + x] + m->logpInsgNoIns, numS + x);
+    for (x = 0; x <= hapSize + 1; x++) {
+        beta_l[numS + x] = obs_l_1[numS + x] + beta_l_1[numS + x] + m->logpInsgIns;
+        bt_l[numS + x] = numS + x;
+    }
+    update_max(&beta_l[0 + numS], &bt_l[0 + numS], obs_l_1[0] + beta_l_1[0] + m->logpNoInsgIns, 0);
+    for (x = 1; x <= hapSize + 1; x++) {
+        int newx = x + 1;
+        if (newx > ROState) newx = ROState;
+        update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[newx] + beta_l_1[newx] + m->logpNoInsgIns, newx);
+    }
+}
+
+static void fbmax_two_dec(const hmm_t *m, double *beta_l, const double *beta_l_1, const double *obs_l_1, int *bt_l)
+{
+    const int hapSize = m->hapSize, numS = m->numS, ROState = m->ROState, numT = m->numT;
+    int x, y;
+    beta_l[ROState] = -HUGE_VAL;
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[ROState] + beta_l_1[ROState] + m->logpLOgLO + m->logpNoInsgNoIns, ROState);
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[hapSize] + beta_l_1[hapSize] + m->logpFirstgLO + m->logpNoInsgNoIns, hapSize);
+    for (x = 1; x <= hapSize; x++) {
+        beta_l[x] = -HUGE_VAL;
+        for (y = 1; y < numT; y++) {
+            int newx = x - y;
+            if (newx < 0) newx = 0;
+            update_max(&beta_l[x], &bt_l[x], obs_l_1[newx] + m->logPTrans[y] + beta_l_1[newx] + m->logpNoInsgNoIns, newx);
+        }
+    }
+    beta_l[0] = obs_l_1[0] + beta_l_1[0] + m->logpNoInsgNoIns;
+    bt_l[0] = 0;
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[numS + ROState] + beta_l_1[numS + ROState] + m->logpLOgLO + m->logpInsgNoIns, numS + ROState);
+    update_max(&beta_l[ROState], &bt_l[ROState], obs_l_1[numS + hapSize] + beta_l_1[numS + hapSize] + m->logpFirstgLO + m->logpInsgNoIns, numS + hapSize);
+    for (x = 0; x <= hapSize; x++) {
+        int newx = x - 1;
+        if (newx < 0) newx = 0;
+        update_max(&beta_l[x], &bt_l[x], obs_l_1[numS + newx] + beta_l_1[numS + newx] + m->logpInsgNoIns, numS + newx);
+    }
+    for (x = 0; x <= hapSize + 1; x++) {
+        beta_l[numS + x] = obs_l_1[numS + x] + beta_l_1[numS + x] + m->logpInsgIns;
+        bt_l[numS + x] = numS + x;
+    }
+    for (x = 0; x <= hapSize + 1; x++)
+        update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[x] + beta_l_1[x] + m->logpNoInsgIns, x);
+}
+
 /* ObservationModelFB::computeBMidPrior — ObservationModelFB.cpp:268-305.  mate == NULL: mapUnmappedReads off or the read
  * is not paired (pinsert stays 0).  Library::getProb — Library.hpp:60-64. */
 static double lib_get_prob(const struct ddo_mate *mt, int x)
@@ -198,13 +267,33 @@ int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, i
     return ddo_pair_mate(hap, Hs, readseq, qual, L, mapQual, readStartU32, hapStart, unmapped, P, NULL, out, hpos);
 }
 
+static int pair_impl(int plain_fbmax, const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                     double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                     const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos);
+
 int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qual, int L,
                   double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
                   const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos)
 {
+    return pair_impl(0, hap, Hs, readseq, qual, L, mapQual, readStartU32, hapStart, unmapped, P, mate, out, hpos);
+}
+
+/* ObservationModelFBMax(hap, read, hapStart, params).calcLikelihood(): KAT cross-check only (see fbmax_two_inc) */
+int ddo_pair_fbmax(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                   double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                   const dd_params *P, ddo_out *out, int *hpos)
+{
+    return pair_impl(1, hap, Hs, readseq, qual, L, mapQual, readStartU32, hapStart, unmapped, P, NULL, out, hpos);
+}
+
+static int pair_impl(int plain_fbmax, const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                     double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                     const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos)
+{
     hmm_t M;
     hmm_t *m = &M;
     int b, x, y;
+    M.plain_fbmax = plain_fbmax;
     memset(out, 0, sizeof(*out));
     out->firstBase = -1;
     out->lastBase = -1;
@@ -287,6 +376,21 @@ int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qu
         m->logProbNoError[Hs - 1] = log(1.0 - perr);
     }
 
+    if (m->plain_fbmax) {   /* ObservationModelFB::setupTransitionProbs — :183-218 */
+        double norm = 0.0;
+        m->logPTrans[0] = 0.0;
+        m->logPTrans[1] = log(1.0 - P->pError);
+        for (x = 1; x < m->numT; x++) if (x != 1) {
+            double pp = -fabs(1.0 - (double)x);
+            m->logPTrans[x] = pp;
+            norm += exp(pp);
+        }
+        norm = log(norm / P->pError);
+        for (x = 1; x < m->numT; x++) if (x != 1) m->logPTrans[x] -= norm;
+        m->logpInsgIns = -1.0;
+        m->logpNoInsgIns = log(1.0 - exp(m->logpInsgIns));
+    }
+
     /* ---- setupReadObservationPotentials — :220-266 ---- */
     for (b = 0; b < L; b++) {
         double rq = qual[b];
@@ -319,9 +423,9 @@ int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qu
 
     /* ---- ObservationModelFBMax::computeForwardMessages — :1569-1581 ---- */
     for (b = 1; b <= m->bMid; b++)
-        pass_two_dec(m, &m->alpha[(size_t)b * T], &m->alpha[(size_t)(b - 1) * T], &m->obs[(size_t)(b - 1) * T], &m->btf[(size_t)b * T]);
+        (m->plain_fbmax ? fbmax_two_dec : pass_two_dec)(m, &m->alpha[(size_t)b * T], &m->alpha[(size_t)(b - 1) * T], &m->obs[(size_t)(b - 1) * T], &m->btf[(size_t)b * T]);
     for (b = L - 1; b > m->bMid; b--)
-        pass_two_inc(m, &m->beta[(size_t)(b - 1) * T], &m->beta[(size_t)b * T], &m->obs[(size_t)b * T], &m->btb[(size_t)(b - 1) * T]);
+        (m->plain_fbmax ? fbmax_two_inc : pass_two_inc)(m, &m->beta[(size_t)(b - 1) * T], &m->beta[(size_t)b * T], &m->obs[(size_t)b * T], &m->btb[(size_t)(b - 1) * T]);
 
     /* ---- ObservationModelFBMax::calcLikelihoodFromLastSlice — :1075-1144 ---- */
     {

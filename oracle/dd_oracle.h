@@ -34,6 +34,11 @@ int ddo_pair_mate(const char *hap, int Hs, const char *readseq, const double *qu
                   double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
                   const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos);
 
+/* sibling model ObservationModelFBMax (not on the production path): only to check its three SURVEY §8(c) values */
+int ddo_pair_fbmax(const char *hap, int Hs, const char *readseq, const double *qual, int L,
+                   double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
+                   const dd_params *P, ddo_out *out, int *hpos);
+
 /* a batch in the product's flat layout; windows [first_window, first_window+n_win) (n_win<0: all) */
 int ddo_batch(const dd_params *P, const dd_batch *B, dd_result *R, int nthreads, int64_t first_window, int64_t n_win);
 

@@ -42,6 +42,7 @@ def load():
                                   C.POINTER(C.c_int)]
         _lib.ddo_pair_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, capi.c_f64p, C.c_int, C.c_double, C.c_uint32,
                                        C.c_uint32, C.POINTER(capi.dd_params), C.POINTER(ddo_out), C.POINTER(C.c_int)]
+        _lib.ddo_pair_fbmax.argtypes = _lib.ddo_pair.argtypes
         _lib.ddo_pair_sums.argtypes = [C.POINTER(capi.dd_batch), capi.c_f64p, capi.c_f64p]
         _lib.ddo_batch.argtypes = [C.POINTER(capi.dd_params), C.POINTER(capi.dd_batch), C.POINTER(capi.dd_result),
                                    C.c_int, C.c_int64, C.c_int64]
@@ -59,6 +60,19 @@ def pair(hap, read, qual, mapQual, read_start, hap_start, params, unmapped=False
     lib.ddo_pair(hap.encode(), len(hap), read.encode(), q.ctypes.data_as(capi.c_f64p), L, float(mapQual),
                  read_start & 0xFFFFFFFF, hap_start & 0xFFFFFFFF, 1 if unmapped else 0, C.byref(params),
                  C.byref(o), hp)
+    return o, list(hp)[:L]
+
+
+def pair_fbmax(hap, read, qual, mapQual, read_start, hap_start, params, unmapped=False):
+    """Sibling model ObservationModelFBMax (KAT cross-check only) -> (ddo_out, hpos list)."""
+    lib = load()
+    L = len(read)
+    q = np.ascontiguousarray(np.broadcast_to(np.asarray(qual, dtype=np.float64), (L,)))
+    hp = (C.c_int * max(L, 1))()
+    o = ddo_out()
+    lib.ddo_pair_fbmax(hap.encode(), len(hap), read.encode(), q.ctypes.data_as(capi.c_f64p), L, float(mapQual),
+                       read_start & 0xFFFFFFFF, hap_start & 0xFFFFFFFF, 1 if unmapped else 0, C.byref(params),
+                       C.byref(o), hp)
     return o, list(hp)[:L]
 
 

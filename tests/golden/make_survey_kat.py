@@ -26,11 +26,12 @@ rng = lambda a, b: list(range(a, b + 1))
 cases = [
     dict(name="S1_struct", hap=S1_HAP, read=S1_READ, pos=0, hapStart=0, q=0.99, mapQual=1 - 1e-16, params=STRUCT,
          ll=-12.208726495298166, llOff=-23.458611539743039, hpos=rng(0, 13) + rng(17, 36),
-         indels=[[14, "-TAT"]], offHap=0, ll_fast=-9.472245272269241),     # ll_fast: ObservationModelS (--faster)
+         indels=[[14, "-TAT"]], offHap=0, ll_fast=-9.472245272269241,       # ll_fast: ObservationModelS (--faster)
+         ll_fbmax=-11.934075176806624),                                    # ll_fbmax: sibling model ObservationModelFBMax
     dict(name="S1_cli", hap=S1_HAP, read=S1_READ, pos=0, hapStart=0, q=0.99, mapQual=1 - 1e-16, params=CLI,
-         ll=-12.206837301998762, llOff=-23.469926307808155, ll_fast=-8.3736536261351855),
+         ll=-12.206837301998762, llOff=-23.469926307808155, ll_fast=-8.3736536261351855, ll_fbmax=-10.342040525271681),
     dict(name="S2_struct", hap=S2_HAP, read=S2_READ, pos=0, hapStart=0, q=0.99, mapQual=1 - 1e-16, params=STRUCT,
-         ll=-0.34501268318605621, hpos=rng(87, 130) + [-4], ll_fast=-0.34673884362349849),
+         ll=-0.34501268318605621, hpos=rng(87, 130) + [-4], ll_fast=-0.34673884362349849, ll_fbmax=-0.35103905873783248),
     dict(name="K1_exact", hap=H, read=r, pos=1010, hapStart=1000, q=0.999, mapQual=1 - 1e-4, params=CLI,
          ll=-0.026245983382989002, llOff=-9.3988325473015166, hpos=rng(10, 39), nBQT=30),
     dict(name="K2_mismatch", hap=H, read=r[:12] + flip[r[12]] + r[13:], pos=1010, hapStart=1000, q=0.999,

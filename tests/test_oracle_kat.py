@@ -99,3 +99,14 @@ def test_oracle_regression_vectors():
         assert f.status == c["fast_status"]
         if f.status == 0:
             assert f.ll.hex() == c["fast_ll"] and fh == c["fast_hpos"]
+
+
+@pytest.mark.parametrize("case", [c for c in KAT if "ll_fbmax" in c], ids=lambda c: c["name"])
+def test_sibling_model_fbmax_kat(case):
+    """SURVEY §8(c) also records ObservationModelFBMax's log-likelihood for S1 / S2.  That model is not on the production
+    path; restating its two message-passing functions lets three more reference numbers pin everything both models share
+    (Init / bMid, emissions, bMid priors, the join, updateMax)."""
+    p = capi.dd_params.from_dict(case["params"])
+    o, _ = _oracle.pair_fbmax(case["hap"], case["read"], case["q"], case["mapQual"], case["pos"], case["hapStart"], p)
+    assert o.status == 0
+    assert o.ll == pytest.approx(case["ll_fbmax"], rel=1e-15, abs=0)
