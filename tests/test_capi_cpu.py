@@ -139,3 +139,29 @@ def test_symbol_lut(lib):
     others = sorted(set("RYacgtnMK"))
     assert [int(lut[ord(c)]) for c in others] == list(range(5, 5 + len(others)))
     assert int(lut[ord("W")]) == 31 and int(lut[ord("S")]) == 31 and int(lut[0]) == 31
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/dindel_hmm.h must be usable from C (the reference-side binding is cgo/JNI/ctypes-like): compile a C99
+    translation unit against it, link the shared library, and call the housekeeping entry points."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include <stdio.h>\n#include "dindel_hmm.h"\n'
+                   'int main(void) {\n'
+                   '  dd_params p; dd_batch b; dd_result r; dd_device_batch db; dd_sizes sz;\n'
+                   '  dd_params_cli_defaults(&p);\n'
+                   '  (void)b; (void)r; (void)db; (void)sz;\n'
+                   '  printf("%d %d %g %d\\n", dd_abi_version(), DD_ABI_VERSION, p.pError, (int)sizeof(dd_batch));\n'
+                   '  return dd_abi_version() == DD_ABI_VERSION ? 0 : 1;\n}\n')
+    exe = tmp_path / "use_abi"
+    libdir = os.path.join(root, "dindel_tgi_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                           "-L", libdir, "-ldindel_hmm", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    import torch
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([str(exe)], env=env).decode().split()
+    assert out[0] == out[1] and float(out[2]) == 5e-4
+    # the ctypes mirror has the same struct size as the C compiler sees
+    assert int(out[3]) == C.sizeof(capi.dd_batch)
