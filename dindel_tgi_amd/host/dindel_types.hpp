@@ -31,6 +31,7 @@ public:
         if (s.size() > 1 && s[0] == '-') { type = DEL; length = int(s.size()) - 1; seq = s.substr(1); }
         else if (s.size() > 1 && s[0] == '+') { type = INS; length = int(s.size()) - 1; seq = s.substr(1); }
         else if (s.size() == 4 && s[1] == '=' && s[2] == '>') { type = SNP; length = 1; seq = s; }
+        else if (s == "*REF") { type = REF; length = 1; seq = s; }           // Variant.hpp:62-65
         else throw std::string("Unrecognized variant");
     }
     const std::string &getString() const { return str; }

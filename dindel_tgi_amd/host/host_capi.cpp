@@ -166,6 +166,25 @@ int ddh_compute_window_faster_json(const char *haps_nl, const char *reads_nl, co
     return compute_window_json(true, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, pd, pi, device, out, cap);
 }
 
+// AlignedVariant mirror next to the reference's class (tests/test_ref_bits.py): returns isCovered, writes type / length / seq
+int ddh_aligned_variant(const char *str, int startHap, int endHap, int startRead, int endRead, int pad, int firstBase, int lastBase,
+                        int *type, int *length, char *seq, int cap)
+{
+    *type = -9; *length = -9; seq[0] = 0;
+    try {
+        AlignedVariant av(std::string(str), startHap, endHap, startRead, endRead);
+        *type = av.getType() == AlignedVariant::INS ? 0 : av.getType() == AlignedVariant::DEL ? 1 : av.getType() == AlignedVariant::SNP ? 2 : 3;
+        *length = av.size();
+        strncpy(seq, av.getSeq().c_str(), size_t(cap - 1));
+        seq[cap - 1] = 0;
+        return av.isCovered(pad, firstBase, lastBase) ? 1 : 0;
+    } catch (std::string &) {
+        return -1;
+    }
+}
+
+double ddh_add_logs(double l1, double l2) { return addLogs(l1, l2); }
+
 // N4: getCIGAR.  out_ops receives (op, len) pairs; returns the number of operations, or -(1+k) for the k-th throw string of
 // {"Haplotype has not been aligned!", "Read is not properly aligned!", "Error(1)!", "Error(2)!", "Error(3)!", "Error(4)!", "How is this possible? (1)"}
 int ddh_get_cigar(const int *hap_ref_pos, int hap_size, const short *hpos, int read_size, int ref_seq_start, int *out_ops, int cap, int *ref_pos)

@@ -153,6 +153,11 @@ static void pass_two_dec(const hmm_t *m, double *beta_l, const double *beta_l_1,
         update_max(&beta_l[numS + x], &bt_l[numS + x], obs_l_1[x] + beta_l_1[x] + m->logpNoInsgIns, x);
 }
 
+/* exported for tests/test_ref_bits.py: the restatement's homopolymer error model and addLogs next to the reference's own */
+static double add_logs(const double l1, const double l2);
+double ddo_hp_error(int hpLen) { return hp_error(hpLen); }
+double ddo_add_logs(double l1, double l2) { return add_logs(l1, l2); }
+
 /* ---- ObservationModelFBMax (the class FBMaxErr derives from; NOT on the production path) --------------------------------
  * Only here because SURVEY §8(c) also lists this model's log-likelihood for S1 / S2: three more reference numbers that pin
  * everything the two models share (Init/bMid, emissions, priors, join, updateMax, traceback).

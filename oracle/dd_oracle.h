@@ -52,6 +52,10 @@ int ddo_batch_fast(const dd_params *P, const dd_batch *B, dd_result *R, int nthr
 /* N1: S[w][h1*H+h2] = sum_r log(0.5)+addLogs(ll[h1][r], ll[h2][r]) (reference DInDel.cpp:3085-3091) */
 int ddo_pair_sums(const dd_batch *B, const double *ll, double *out);
 
+/* pieces exported for the check against oracle/_ref (reference headers compiled as they are) */
+double ddo_hp_error(int hpLen);
+double ddo_add_logs(double l1, double l2);
+
 #ifdef __cplusplus
 }
 #endif
