@@ -239,8 +239,9 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
 /* Same batch in, same result layout out, but each pair is scored by ObservationModelS(hap, read, hapStart,
  * params).align(HapHash(4, hap)) — DetInDel::computeLikelihoodsFaster, reference DInDel.cpp:1790-1833
  * (Faster.cpp:42-681, Haplotype.hpp:315-384).  That model fills ll, hpos, firstBase, lastBase and the coverage
- * flags; offHap / offHapHMQ are always 0 (Faster.cpp:491,:529) and llOn, llOff, mLogBQ and the counters stay 0, as
- * MLAlignment's constructor leaves them.  Params used: pError, pMut, maxLengthDel (size check only), padCover,
+ * flags; offHap / offHapHMQ are always 0 (Faster.cpp:491,:529); llOn, llOff, numIndels, numMismatch stay 0 as MLAlignment's
+ * constructor sets them (MLAlignment.hpp:35-46), and mLogBQ, nBQT, nmmBQT, nMMLeft, nMMRight — which that constructor leaves
+ * uninitialised and this model never assigns — are reported as 0.  Params used: pError, pMut, maxLengthDel (size check only), padCover,
  * capMapQualFast, maxMismatch.  status: DD_PAIR_HAPSIZE (`throw string("hapSize error.")`, Faster.cpp:47) or
  * DD_PAIR_NAN for a read shorter than the 4-mer (`throw string("HapHash string too short")`, Haplotype.hpp:341). */
 int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_result *r, int device);

@@ -6,6 +6,8 @@
 //   ReadIndelErrorModel.hpp  getViterbiHPError    — the homopolymer indel-error model behind logProbError[] (A3)
 //   Utils.hpp                addLogs              — the genotype read-sum term (N1)
 //   Variant.hpp              AlignedVariant       — string forms, isCovered (hapIndelCovered / hapSNPCovered, A10)
+//   ObservationModel.hpp     ObservationModelParameters::setDefaultValues — the struct defaults behind dd_params
+//   MLAlignment.hpp          the hpos codes INS / DEL / LO / RO and what the constructor zeroes (A11)
 // This file only includes them (path given by -I on the command line, see Makefile target _ref) and exports C wrappers;
 // the library goes to oracle/_ref/ and is used by tests/test_ref_bits.py to check the restatement and the host tables
 // against the reference's own code.  TEST INFRASTRUCTURE ONLY.
@@ -17,6 +19,8 @@ using namespace std;          // ReadIndelErrorModel.hpp relies on the including
 #include "ReadIndelErrorModel.hpp"
 #include "Utils.hpp"
 #include "Variant.hpp"
+#include "MLAlignment.hpp"
+#include "ObservationModel.hpp"
 
 extern "C" {
 
@@ -41,6 +45,26 @@ int ref_aligned_variant(const char *str, int startHap, int endHap, int startRead
     seq[cap - 1] = 0;
     return av.isCovered(pad, firstBase, lastBase) ? 1 : 0;
     } catch (string &) { return -1; }      // "Unrecognized variant" (Variant.hpp:68)
+}
+
+
+// ObservationModelParameters() — ObservationModel.hpp:31-64: d = {pError, pMut, pFirstgLO, mapQualThreshold, checkBaseQualThreshold,
+// capMapQualFast}, i = {maxLengthDel, maxLengthIndel, padCover, bMid, forceReadOnHaplotype, mapUnmappedReads, maxMismatch}
+void ref_obs_params_defaults(double *d, int *i)
+{
+    ObservationModelParameters p;
+    d[0] = p.pError; d[1] = p.pMut; d[2] = p.pFirstgLO; d[3] = p.mapQualThreshold; d[4] = p.checkBaseQualThreshold; d[5] = p.capMapQualFast;
+    i[0] = p.maxLengthDel; i[1] = p.maxLengthIndel; i[2] = p.padCover; i[3] = p.bMid; i[4] = p.forceReadOnHaplotype; i[5] = p.mapUnmappedReads;
+    i[6] = p.maxMismatch;
+}
+
+// MLAlignment codes and constructor values — MLAlignment.hpp:31-46
+void ref_mlalignment(int *codes, double *d, int *i)
+{
+    MLAlignment ml;
+    codes[0] = MLAlignment::INS; codes[1] = MLAlignment::DEL; codes[2] = MLAlignment::LO; codes[3] = MLAlignment::RO;
+    d[0] = ml.ll; d[1] = ml.llOn; d[2] = ml.llOff;
+    i[0] = ml.offHap; i[1] = ml.offHapHMQ; i[2] = ml.numIndels; i[3] = ml.numMismatch; i[4] = ml.relPos;
 }
 
 }

@@ -77,3 +77,18 @@ def test_aligned_variant_mirror(ref):
             assert got == want, (s, args, got, want)           # includes -1: both throw "Unrecognized variant" (Variant.hpp:68)
             n_ok += got[0] >= 0
     assert n_ok > 200
+
+
+def test_struct_defaults_and_hpos_codes(ref, lib):
+    """ObservationModelParameters::setDefaultValues (ObservationModel.hpp:39-64) against dd_params_struct_defaults, and the
+    MLAlignment hpos codes / constructor zeros (MLAlignment.hpp:31-46) against the header's DD_HPOS_* values."""
+    d = (C.c_double * 6)(); i = (C.c_int * 7)()
+    ref.ref_obs_params_defaults(d, i)
+    p = capi.dd_params()
+    lib.dd_params_struct_defaults(C.byref(p))
+    assert [p.pError, p.pMut, p.pFirstgLO, p.mapQualThreshold, p.checkBaseQualThreshold, p.capMapQualFast] == list(d)
+    assert [p.maxLengthDel, p.maxLengthDel, p.padCover, p.bMid, p.forceReadOnHaplotype, p.mapUnmappedReads, p.maxMismatch] == list(i)
+    codes = (C.c_int * 4)(); dd = (C.c_double * 3)(); ii = (C.c_int * 5)()
+    ref.ref_mlalignment(codes, dd, ii)
+    assert list(codes) == [-1, -2, -3, -4]            # DD_HPOS_INS, DD_HPOS_DEL, DD_HPOS_LO, DD_HPOS_RO (include/dindel_hmm.h)
+    assert list(dd) == [0.0, 0.0, 0.0] and list(ii) == [0, 0, 0, 0, -1]
