@@ -60,6 +60,26 @@ def test_ragged_and_empty_windows(lib):
     pb, got = check(lib, ws)
     assert pb.n_pairs == 2 * 7 + 0 + 0 + 3 * 3
     assert got["onHap"][7:10].tolist() == [0, 0, 0]                 # reads of the hap-less window
+    # the same degenerate windows through the --faster model and the N1 entry points
+    from tests.test_gpu_faster import assert_same_faster, run_faster
+    p = capi.params_cli_defaults()
+    assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=4, faster=True), pb)
+    b = pb.ctypes_batch()
+    hh = np.zeros(pb.n_windows + 1, np.int64)
+    assert lib.dd_pair_sum_offsets(C.byref(b), hh.ctypes.data_as(capi.c_i64p)) == 0
+    assert hh.tolist() == [0, 4, 5, 5, 14]
+    ns = int(hh[-1])
+    prior = np.zeros(ns); filt = np.zeros(pb.n_haps, np.uint8); nc = np.ones(pb.n_haps, np.int32)
+    sums = np.zeros(ns); post = np.zeros(ns); pairs = np.zeros(4 * pb.n_windows, np.int32); vals = np.zeros(3 * pb.n_windows)
+    rc = lib.dd_map_pairs(C.byref(b), got["ll"].ctypes.data_as(capi.c_f64p), prior.ctypes.data_as(capi.c_f64p),
+                          filt.ctypes.data_as(C.POINTER(C.c_uint8)), nc.ctypes.data_as(capi.c_i32p), sums.ctypes.data_as(capi.c_f64p),
+                          post.ctypes.data_as(capi.c_f64p), pairs.ctypes.data_as(capi.c_i32p), vals.ctypes.data_as(capi.c_f64p), 0)
+    assert rc == 0, capi.last_error()
+    assert sums[4] == 0.0                                           # the read-less window: an empty sum
+    assert pairs[8:12].tolist() == [-1, -1, -1, -1]                 # the haplotype-less window: no pair at all
+    want = np.zeros(ns)
+    _oracle.load().ddo_pair_sums(C.byref(b), got["ll"].ctypes.data_as(capi.c_f64p), want.ctypes.data_as(capi.c_f64p))
+    np.testing.assert_allclose(sums, want, rtol=1e-12, atol=0)
 
 
 def test_n_bases_and_iupac_in_reads(lib):
