@@ -81,7 +81,16 @@ def cpu_baseline(pb, params, seconds_target=15.0, faster=False):
     rl = np.diff(a["read_seq_off"]).astype(np.int64)
     for w in range(n_win):
         cells += int(hl[a["win_hap_off"][w]:a["win_hap_off"][w + 1]].sum()) * int(rl[a["win_read_off"][w]:a["win_read_off"][w + 1]].sum())
-    return dict(value=cells / dt, unit="cells/s", cores=threads, kind="port",
+    # the same restatement on ONE thread, on a smaller sample (SURVEY §8(d) asks for both figures)
+    n1 = max(1, min(pb.n_windows, int(3.0 / max(per_win * threads, 1e-9))))
+    t0 = time.time()
+    _oracle.batch(params, pb, nthreads=1, first_window=0, n_win=n1, faster=faster)
+    dt1 = time.time() - t0
+    cells1 = 0
+    for w in range(n1):
+        cells1 += int(hl[a["win_hap_off"][w]:a["win_hap_off"][w + 1]].sum()) * int(rl[a["win_read_off"][w]:a["win_read_off"][w + 1]].sum())
+    return dict(value=cells / dt, unit="cells/s", cores=threads, kind="port", value_1_thread=cells1 / dt1,
+                sample_1_thread="first %d windows, %.1f s" % (n1, dt1),
                 sample="first %d of the %d windows (%d pairs), oracle/dd_oracle.c with %d OpenMP threads, %.1f s"
                        % (n_win, pb.n_windows, int(pb.win_pair_off[n_win]), threads, dt),
                 windows_per_s=n_win / dt)
