@@ -205,3 +205,41 @@ def test_engine_fast_unpack_equals_full_rebuild():
             assert ml["mLogBQ"] == pytest.approx(full["mLogBQ"], rel=1e-15, abs=0)
             n_plain += (not ml["indels"] and not ml["snps"])
     assert 20 < n_plain < len(haps) * len(reads)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_engine_random_windows_both_models(seed):
+    """Adversarial windows (tests/test_gpu_fuzz.make_windows: tiny alphabets, N / IUPAC bytes, indel-carrying and junk reads,
+    reads hanging off either end) through LikelihoodEngine: every record equals the oracle's values and, for the main
+    model, what rebuildAlignment derives from the same hpos (this exercises the counter + memcmp fast path of the unpack)."""
+    from tests.test_gpu_fuzz import make_windows
+    rng = np.random.default_rng(7000 + seed)
+    p = capi.params_cli_defaults() if seed % 2 else capi.params_struct_defaults()
+    n_pairs = 0
+    for w in make_windows(rng, 6, 90, 70, min_hap=p.maxLengthDel):
+        reads = [r.seq for r in w.reads]
+        quals = [list(r.qual) for r in w.reads]
+        mapq = [r.mapQual for r in w.reads]
+        pos = [float(r.start) for r in w.reads]
+        um = [int(r.unmapped) for r in w.reads]
+        res = _host.compute_window(w.haps, reads, quals, mapq, pos, um, w.hap_start, p)
+        resf = _host.compute_window(w.haps, reads, quals, mapq, pos, um, w.hap_start, p, faster=True)
+        for h, hap in enumerate(w.haps):
+            for r, rd in enumerate(w.reads):
+                o, hpos = _oracle.pair(hap, rd.seq, rd.qual, rd.mapQual, rd.start, w.hap_start, p, unmapped=rd.unmapped)
+                ml = res["liks"][h][r]
+                assert (ml["ll"], ml["llOn"], ml["llOff"]) == (o.ll, o.llOn, o.llOff) and ml["hpos"] == hpos
+                assert (ml["numIndels"], ml["numMismatch"], ml["nBQT"], ml["nmmBQT"], ml["nMMLeft"], ml["nMMRight"]) == \
+                    (o.numIndels, o.numMismatch, o.nBQT, o.nmmBQT, o.nMMLeft, o.nMMRight)
+                assert (ml["firstBase"], ml["lastBase"], ml["offHap"], ml["offHapHMQ"]) == (o.firstBase, o.lastBase, o.offHap, o.offHapHMQ)
+                full = _host.rebuild(hap, rd.seq, rd.qual, hpos, p)
+                for k in ("align", "indels", "snps"):
+                    assert ml[k] == full[k], (h, r, k)
+                if "liks" in resf:
+                    f, fh = _oracle.pair_fast(hap, rd.seq, rd.qual, rd.mapQual, rd.start, w.hap_start, p)
+                    mf = resf["liks"][h][r]
+                    assert mf["ll"] == f.ll and mf["hpos"] == fh and (mf["firstBase"], mf["lastBase"]) == (f.firstBase, f.lastBase)
+                n_pairs += 1
+        if any(len(r.seq) < 4 for r in w.reads):
+            assert resf == {"throw": "HapHash string too short"}, (str(resf)[:300], [len(r.seq) for r in w.reads], [len(h) for h in w.haps])
+    assert n_pairs > 15
