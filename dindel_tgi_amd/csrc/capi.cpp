@@ -138,10 +138,11 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     // HBM scratch costs a coalesced row fetch per 8 traceback steps and (D=11) block-shared constants; the LDS tile
     // costs occupancy.  Measured over six shapes (tools/ab_point.py with DD_FORCE_GBT=0/1): the LDS build wins
     // whenever its tile still lets the CU hold as many waves as its registers allow, the scratch build wins
-    // (5-80 %) once LDS caps it at <= 3/4 of that.
+    // (5-80 %) once LDS caps it below that (tools/plan_check.py grid: at 10 of 12 waves the scratch build is already
+    // 14 % ahead).
     // For K >= 3 the scratch build is also the register-lean one (block-shared constants) and wins at every
     // shape measured (+26 ... +41 %).
-    pl.gbt = best[0] == 0 || (pl.K >= 3 && best[1] > 0) || 4 * best[0] <= 3 * cap[0];
+    pl.gbt = best[0] == 0 || (pl.K >= 3 && best[1] > 0) || best[0] < cap[0];
     if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
         if (f[0] == '1' && best[1] > 0) pl.gbt = true;
         if (f[0] == '0' && best[0] > 0) pl.gbt = false;

@@ -27,7 +27,7 @@ def time_point(pb, p):
 
 bad = 0
 for mld in (5, 10):
-    for L in (36, 76, 100, 150, 250, 400, 700, 1000):
+    for L in (36, 76, 100, 110, 120, 130, 140, 150, 250, 400, 700, 1000):
         for hap in (40, 120, 180, 250, 380, 500, 760):
             pairs_target = 2.5e5 * (100 * 120) / (L * hap)
             R = 100
