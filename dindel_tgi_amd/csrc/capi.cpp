@@ -505,6 +505,22 @@ struct LenClass {
 // which per-pair model an entry point runs
 enum Model { MODEL_FBMAXERR = 0 /* ObservationModelFBMaxErr, computeLikelihoods */, MODEL_S = 1 /* ObservationModelS, computeLikelihoodsFaster */ };
 
+// Waves per workgroup for windows with `units` units of work per haplotype (reads for the main kernel, groups of pairs for
+// the --faster one): a workgroup's waves take the units round-robin, so with few units some waves idle in the last round
+// while the workgroup's LDS stays allocated.  Keep `maxw` unless a smaller workgroup uses its waves > 10 % better
+// (tools/coverage_sweep.py: 2 reads per window ran at half the rate with 4-wave workgroups).
+static int waves_for_reads(int64_t units, int maxw)
+{
+    if (units < 1) units = 1;
+    int best = maxw;
+    double bestu = (double)units / (double)(((units + maxw - 1) / maxw) * maxw);
+    for (int w = maxw - 1; w >= 1; w--) {
+        const double u = (double)units / (double)(((units + w - 1) / w) * w);
+        if (u > bestu * 1.10) { best = w; bestu = u; }
+    }
+    return best;
+}
+
 // --faster model LDS: block-shared haplotype index + per-pair areas (layout in faster_kernel.hip's header)
 static size_t lds_layout_fast(int max_hap_len, int max_read_len, int n_qual, int &waves, int &groups, ddk::KernelArgs &A)
 {
@@ -556,12 +572,19 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
 {
     (void)p;
     int waves = DD_WAVES, groups = 4;
-    const size_t lds = lds_layout_fast(b->max_hap_len, b->max_read_len, b->n_qual, waves, groups, A);
+    size_t lds = lds_layout_fast(b->max_hap_len, b->max_read_len, b->n_qual, waves, groups, A);
     if (lds > (size_t)160 * 1024) return fail(DD_ERR_UNSUPPORTED, "shape exceeds the LDS tile of the --faster kernel");
     A.n_qual = b->n_qual;
     A.fast_groups = groups;
     const int64_t target_blocks = 8192;
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    {   // thin windows: no more wavefronts per workgroup than the windows have groups of `groups` reads
+        const int w2 = waves_for_reads((avg_reads + groups - 1) / groups, waves);
+        if (w2 != waves) {
+            waves = w2;
+            lds = (size_t)A.lds_shared_bytes + (size_t)waves * (groups < 4 ? groups + 1 : 4) * A.lds_wave_bytes;
+        }
+    }
     int64_t max_split = (avg_reads + waves * groups - 1) / (waves * groups);
     if (max_split < 1) max_split = 1;
     int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
@@ -626,8 +649,19 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     A.hap_list = lc ? lc->hap_list : nullptr;
     A.len_min = lc ? lc->min_read_len : 0;
     A.len_max = lc ? lc->max_read_len : 0x7fffffff;
-    const int K = pl.K, Dt = pl.Dt, waves = pl.waves;
-    const size_t lds = pl.lds;
+    const int K = pl.K, Dt = pl.Dt;
+    int waves = pl.waves;
+    size_t lds = pl.lds;
+    // thin windows: a wavefront works on one read at a time, so a workgroup never needs more waves than the windows have
+    // reads (tools/coverage_sweep.py: 2 reads per window ran at half the rate with idle waves in every workgroup)
+    const int64_t avg_reads_w = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    {
+        const int w2 = waves_for_reads(avg_reads_w, waves);
+        if (w2 != waves) {
+            waves = w2;
+            lds = lds_layout(K, Dt, cls_read, b->n_qual, waves, pl.gbt, A);
+        }
+    }
     if (pl.gbt) {
         if (!workspace || workspace_bytes < pl.scratch_bytes)
             return fail(DD_ERR_INVALID, "workspace too small for this shape: allocate dd_workspace_bytes() bytes");
