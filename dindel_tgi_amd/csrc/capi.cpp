@@ -521,6 +521,29 @@ static int waves_for_reads(int64_t units, int maxw)
     return best;
 }
 
+// Read split of a haplotype over workgroups.  One workgroup per haplotype is the cheapest (the per-haplotype setup is done
+// once), but a small batch has too few haplotypes to fill the chip, and a split that leaves the workgroup's `waves` waves a
+// ragged number of rounds wastes wave slots (tools/batch_size_sweep.py).  Take the smallest split that yields `min_blocks`
+// workgroups with >= 90 % of the wave slots used; failing that, the best-filled split at or above the needed one.
+static int64_t pick_split(int64_t n_haps, int64_t units, int waves, int64_t min_blocks)
+{
+    if (units < 1) units = 1;
+    if (n_haps < 1) n_haps = 1;
+    const int64_t max_split = (units + waves - 1) / waves;
+    int64_t need = (min_blocks + n_haps - 1) / n_haps;
+    if (need < 1) need = 1;
+    if (need > max_split) need = max_split;
+    int64_t best = need;
+    double bestu = -1.0;
+    for (int64_t sp = need; sp <= max_split; sp++) {
+        const int64_t slots = sp * waves;
+        const double u = (double)units / (double)(slots * ((units + slots - 1) / slots));
+        if (u >= 0.9) return sp;
+        if (u > bestu) { bestu = u; best = sp; }
+    }
+    return best;
+}
+
 // --faster model LDS: block-shared haplotype index + per-pair areas (layout in faster_kernel.hip's header)
 static size_t lds_layout_fast(int max_hap_len, int max_read_len, int n_qual, int &waves, int &groups, ddk::KernelArgs &A)
 {
@@ -576,7 +599,8 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
     if (lds > (size_t)160 * 1024) return fail(DD_ERR_UNSUPPORTED, "shape exceeds the LDS tile of the --faster kernel");
     A.n_qual = b->n_qual;
     A.fast_groups = groups;
-    const int64_t target_blocks = 8192;
+    int64_t target_blocks = 1024;                 // workgroups wanted before haplotypes are split (A/B: DD_FAST_TARGET_BLOCKS)
+    if (const char *e = getenv("DD_FAST_TARGET_BLOCKS")) { const long v = atol(e); if (v >= 1) target_blocks = v; }   // A/B only
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
     {   // thin windows: no more wavefronts per workgroup than the windows have groups of `groups` reads
         const int w2 = waves_for_reads((avg_reads + groups - 1) / groups, waves);
@@ -585,11 +609,7 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
             lds = (size_t)A.lds_shared_bytes + (size_t)waves * (groups < 4 ? groups + 1 : 4) * A.lds_wave_bytes;
         }
     }
-    int64_t max_split = (avg_reads + waves * groups - 1) / (waves * groups);
-    if (max_split < 1) max_split = 1;
-    int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
+    const int64_t split = pick_split(b->n_haps, (avg_reads + groups - 1) / groups, waves, target_blocks);
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.n_split = (int32_t)split;
     A.item_begin = (int32_t)(hap_begin * split);
@@ -669,13 +689,10 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
         A.bt_rows = cls_read;
     }
     // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
-    const int64_t target_blocks = 4096;
+    int64_t target_blocks = 4096;
+    if (const char *e = getenv("DD_TARGET_BLOCKS")) { const long v = atol(e); if (v >= 1) target_blocks = v; }   // A/B only
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
-    int64_t max_split = (avg_reads + waves - 1) / waves;
-    if (max_split < 1) max_split = 1;
-    int64_t split = (target_blocks + b->n_haps - 1) / b->n_haps;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
+    const int64_t split = pick_split(b->n_haps, avg_reads, waves, target_blocks);
     A.n_split = (int32_t)split;
     if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
     if (lc && lc->hap_list) { hap_begin = lc->list_begin; hap_end = lc->list_end; }   // positions in the class list
