@@ -934,7 +934,8 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     // (HBM-scratch build).  Finer read classes cost more in repeated per-haplotype setup than they gain
     // (tools/ragged_bench.py: 5000 ragged windows 0.2125 s with haplotype classes only, 0.2532 s with five read classes,
     // 0.2455 s with one batch-wide plan).
-    static const int kReadBounds[] = {160, DD_MAX_READ_LEN};
+    int kReadBounds[] = {160, DD_MAX_READ_LEN};
+    if (const char *e = getenv("DD_READ_BOUND")) { const int v = atoi(e); if (v >= 1 && v < DD_MAX_READ_LEN) kReadBounds[0] = v; }   // A/B only
     struct HostClass { std::vector<int32_t> haps; int max_hap = 0; const int32_t *dev = nullptr; };
     std::vector<HostClass> hcls(sizeof(kHapBounds) / sizeof(int));
     for (int64_t h = 0; h < sz.n_haps; h++) {
