@@ -705,7 +705,11 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
         if (r->onHap && r->offHapHMQ && lc && lc->run_onhap) HIP_TRY(ddk::launch_onhap(A, static_cast<hipStream_t>(stream)));
         return DD_SUCCESS;
     }
-    if (pl.grid_cap && grid > pl.grid_cap) grid = pl.grid_cap;
+    if (pl.grid_cap) {
+        // the scratch holds grid_cap x pl.waves back-pointer tiles; smaller workgroups (thin windows) may be more numerous
+        const int64_t cap = (int64_t)pl.grid_cap * pl.waves / waves;
+        if (grid > cap) grid = cap;
+    }
     g_last_launch[0] = K; g_last_launch[1] = Dt + (pl.gbt ? 100 : 0); g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
