@@ -93,7 +93,13 @@ class dd_device_batch(C.Structure):
                 ("win_varcov_off", C.c_void_p), ("tables", C.c_void_p),
                 ("n_qual", C.c_int32), ("n_mapq", C.c_int32), ("hap_var_flank", C.c_void_p), ("sym_lut", C.c_void_p),
                 ("read_mate_pos", C.c_void_p), ("read_mate_len", C.c_void_p), ("read_lib", C.c_void_p),
-                ("lib_off", C.c_void_p), ("lib_logprob", C.c_void_p), ("lib_log95", C.c_void_p)]
+                ("lib_off", C.c_void_p), ("lib_logprob", C.c_void_p), ("lib_log95", C.c_void_p),
+                ("hap_class_list", C.c_void_p), ("classes", C.c_void_p)]
+
+
+class dd_length_classes(C.Structure):
+    _fields_ = [("hap_class_off", C.c_int32 * 8), ("hap_class_max", C.c_int32 * 7), ("n_read_classes", C.c_int32),
+                ("read_class_lo", C.c_int32 * 2), ("read_class_max", C.c_int32 * 2)]
 
 
 class dd_device_result(C.Structure):
@@ -102,7 +108,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
-           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -138,6 +144,7 @@ def load():
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_symbol_lut.argtypes = [C.POINTER(dd_batch), C.POINTER(C.c_uint8)]
     lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
+    lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_i32p, C.POINTER(dd_length_classes)]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]
     lib.dd_workspace_bytes.restype = C.c_size_t

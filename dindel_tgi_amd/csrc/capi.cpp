@@ -480,6 +480,44 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
     return T_END;
 }
 
+static const int kHapClassBounds[DD_N_HAP_CLASSES] = {62, 126, 190, 254, 382, 510, DD_MAX_HAP_LEN};   // 64*K - 2
+static const int kReadClassBounds[2] = {160, DD_MAX_READ_LEN};
+
+int dd_build_length_classes(const dd_batch *b, int32_t *hap_class_list, dd_length_classes *out)
+{
+    if (!b || !hap_class_list || !out) return fail(DD_ERR_INVALID, "null argument");
+    dd_sizes sz;
+    int rc = dd_batch_sizes(b, &sz);
+    if (rc) return rc;
+    memset(out, 0, sizeof(*out));
+    if (sz.max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766");
+    std::vector<int> cls((size_t)sz.n_haps);
+    int count[DD_N_HAP_CLASSES] = {0};
+    for (int64_t h = 0; h < sz.n_haps; h++) {
+        const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+        int c = 0;
+        while (len > kHapClassBounds[c]) c++;
+        cls[(size_t)h] = c;
+        count[c]++;
+        if (len > out->hap_class_max[c]) out->hap_class_max[c] = len;
+    }
+    for (int c = 0; c < DD_N_HAP_CLASSES; c++) out->hap_class_off[c + 1] = out->hap_class_off[c] + count[c];
+    int fill[DD_N_HAP_CLASSES];
+    for (int c = 0; c < DD_N_HAP_CLASSES; c++) fill[c] = out->hap_class_off[c];
+    for (int64_t h = 0; h < sz.n_haps; h++) hap_class_list[fill[cls[(size_t)h]]++] = (int32_t)h;
+    int lo = 1;
+    for (int k = 0; k < 2; k++) {
+        int mx = 0;
+        for (int64_t q = 0; q < sz.n_reads; q++) {
+            const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+            if (len >= lo && len <= kReadClassBounds[k] && len > mx) mx = len;
+        }
+        if (mx) { out->read_class_lo[out->n_read_classes] = lo; out->read_class_max[out->n_read_classes] = mx; out->n_read_classes++; }
+        lo = kReadClassBounds[k] + 1;
+    }
+    return DD_SUCCESS;
+}
+
 size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
 {
     if (!p || !b || check_params(p) != DD_SUCCESS) return 0;
@@ -488,7 +526,17 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
     ddk::KernelArgs A;
     memset(&A, 0, sizeof(A));
     if (make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A) != DD_SUCCESS) return 0;
-    return pl.scratch_bytes;
+    size_t bytes = pl.scratch_bytes;
+    if (b->classes && b->hap_class_list)          // per-class launches: the largest scratch any (haplotype, read) class needs
+        for (int c = 0; c < DD_N_HAP_CLASSES; c++)
+            for (int k = 0; k < b->classes->n_read_classes && b->classes->hap_class_max[c] > 0; k++) {
+                ddk::KernelArgs A2;
+                memset(&A2, 0, sizeof(A2));
+                if (make_plan(p, b->classes->hap_class_max[c], b->classes->read_class_max[k], b->n_qual, pl, A2) == DD_SUCCESS &&
+                    pl.scratch_bytes > bytes)
+                    bytes = pl.scratch_bytes;
+            }
+    return bytes;
 }
 
 // Enqueue the path for haplotypes [hap_begin, hap_end) and reads [read_begin, read_end) of the batch (a
@@ -721,6 +769,31 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
 
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (b && b->classes && b->hap_class_list) {
+        // ragged batch: one launch per non-empty (haplotype class, read class), onHap once at the end
+        const dd_length_classes *C = b->classes;
+        int total = 0, launched = 0;
+        for (int c = 0; c < DD_N_HAP_CLASSES; c++)
+            if (C->hap_class_off[c + 1] > C->hap_class_off[c]) total += C->n_read_classes;
+        if (total > 1) {
+            for (int c = 0; c < DD_N_HAP_CLASSES; c++) {
+                if (C->hap_class_off[c + 1] <= C->hap_class_off[c]) continue;
+                LenClass lc;
+                lc.hap_list = b->hap_class_list;
+                lc.list_begin = C->hap_class_off[c];
+                lc.list_end = C->hap_class_off[c + 1];
+                lc.max_hap_len = C->hap_class_max[c];
+                for (int k = 0; k < C->n_read_classes; k++) {
+                    lc.min_read_len = C->read_class_lo[k];
+                    lc.max_read_len = C->read_class_max[k];
+                    lc.run_onhap = (++launched == total);
+                    const int rc = launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, b->n_haps, 0, b->n_reads, &lc);
+                    if (rc) return rc;
+                }
+            }
+            return DD_SUCCESS;
+        }
+    }
     return launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
 }
 
@@ -933,15 +1006,15 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     // Ragged batches: haplotypes are grouped by the lane tiling they need (K) and reads by length class, and each
     // non-empty (K class, length class) gets its own launches — a single 170-bp haplotype or 250-bp read no longer
     // drags every pair of the batch onto the K=3 / long-read build.
-    static const int kHapBounds[] = {62, 126, 190, 254, 382, 510, DD_MAX_HAP_LEN};          // 64*K - 2
+    const int *kHapBounds = kHapClassBounds;
     // reads: one class up to 160 bp (LDS back-pointer tile still leaves >= 8 waves per CU), one for longer reads
     // (HBM-scratch build).  Finer read classes cost more in repeated per-haplotype setup than they gain
     // (tools/ragged_bench.py: 5000 ragged windows 0.2125 s with haplotype classes only, 0.2532 s with five read classes,
     // 0.2455 s with one batch-wide plan).
-    int kReadBounds[] = {160, DD_MAX_READ_LEN};
+    int kReadBounds[] = {kReadClassBounds[0], kReadClassBounds[1]};
     if (const char *e = getenv("DD_READ_BOUND")) { const int v = atoi(e); if (v >= 1 && v < DD_MAX_READ_LEN) kReadBounds[0] = v; }   // A/B only
     struct HostClass { std::vector<int32_t> haps; int max_hap = 0; const int32_t *dev = nullptr; };
-    std::vector<HostClass> hcls(sizeof(kHapBounds) / sizeof(int));
+    std::vector<HostClass> hcls(DD_N_HAP_CLASSES);
     for (int64_t h = 0; h < sz.n_haps; h++) {
         const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
         size_t c = 0;

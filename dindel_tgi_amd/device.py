@@ -67,6 +67,12 @@ class DeviceBatch:
             t["lib_log95"] = _to_dev(l95, self.device)
         if pb.hap_var_flank is not None and len(pb.hap_var_flank):
             t["hap_var_flank"] = _to_dev(pb.hap_var_flank, self.device)
+        # ragged batches: per-class launch plans (haplotype length x read length), as the host-pointer path does by itself
+        self.classes = capi.dd_length_classes()
+        hcl = np.zeros(max(pb.n_haps, 1), np.int32)
+        if lib.dd_build_length_classes(C.byref(hb), hcl.ctypes.data_as(capi.c_i32p), C.byref(self.classes)) != 0:
+            raise RuntimeError("dd_build_length_classes: " + capi.last_error())
+        t["hap_class_list"] = _to_dev(hcl, self.device)
         self.t = t
         db = capi.dd_device_batch()
         db.n_windows, db.n_haps, db.n_reads = pb.n_windows, pb.n_haps, pb.n_reads
@@ -74,6 +80,7 @@ class DeviceBatch:
         for k, v in t.items():
             setattr(db, k, v.data_ptr())
         db.n_qual, db.n_mapq = hb.n_qual, hb.n_mapq
+        db.classes = C.addressof(self.classes)
         self.db = db
         # results
         n = result_lengths(pb)

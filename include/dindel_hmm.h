@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 7
+#define DD_ABI_VERSION 8
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -209,6 +209,20 @@ int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log9
 int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off,
                    int64_t *win_hpos_off, int64_t *win_varcov_off);
 
+/* Ragged batches: haplotypes are grouped by the lane tiling they need and reads into "<= 160 bp" / "longer"; every
+ * non-empty (haplotype class, read class) gets its own launch plan, so one long haplotype or read does not put the whole
+ * batch on the slower build.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the
+ * summary once on the host (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
+#define DD_N_HAP_CLASSES 7
+typedef struct dd_length_classes {
+    int32_t hap_class_off[DD_N_HAP_CLASSES + 1];  /* class c owns hap_class_list[hap_class_off[c] .. hap_class_off[c+1])   */
+    int32_t hap_class_max[DD_N_HAP_CLASSES];      /* longest haplotype of the class (0 = empty class)                      */
+    int32_t n_read_classes;                       /* 0..2                                                                  */
+    int32_t read_class_lo[2], read_class_max[2];  /* shortest admissible / longest present read length of each read class  */
+} dd_length_classes;
+/* hap_class_list[n_haps]: haplotype indices sorted by class, ascending inside a class (host memory; copy it to the device) */
+int dd_build_length_classes(const dd_batch *b, int32_t *hap_class_list, dd_length_classes *out);
+
 typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_batch */
     int32_t n_windows, n_haps, n_reads;
     int32_t max_hap_len, max_read_len;
@@ -225,6 +239,9 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
      * dd_build_library_tables */
     const int32_t *read_mate_pos, *read_mate_len; const uint8_t *read_lib;
     const int32_t *lib_off; const double *lib_logprob, *lib_log95;
+    /* optional, both or neither: per-class launches for ragged batches (main model only) */
+    const int32_t *hap_class_list;          /* DEVICE copy of dd_build_length_classes' list */
+    const dd_length_classes *classes;       /* HOST pointer */
 } dd_device_batch;
 
 /* bytes of device scratch dd_launch_device needs for this shape (0 if none) */

@@ -324,3 +324,28 @@ def test_iupac_and_soft_masked_haplotype_bytes(lib):
     pb = pack(wins)
     p = capi.params_cli_defaults()
     assert_same_faster(run_faster(lib, p, pb), _oracle.batch(p, pb, nthreads=8, faster=True), pb)
+
+
+def test_device_pointer_path_uses_length_classes(lib):
+    """dd_launch_device with the dd_build_length_classes summary: a ragged batch (haplotypes 40…400 bp, reads 30…300 bp)
+    gets per-class plans and still equals the oracle; the class summary itself is checked against numpy."""
+    import torch
+    from dindel_tgi_amd.device import DeviceBatch
+    wins = []
+    for hl, L in ((50, 36), (120, 100), (170, 100), (120, 250), (300, 150), (400, 300), (61, 30), (63, 161)):
+        hap = rnd(hl)
+        wins.append(Window(1000, [hap, hap[:hl // 2] + hap[hl // 2 + 2:]], reads_from(hap, 9, L)))
+    pb = pack(wins)
+    p = capi.params_cli_defaults()
+    dev = DeviceBatch(pb, p, "cuda:0")
+    c = dev.classes
+    hl = np.diff(pb.a["hap_seq_off"])
+    bounds = [62, 126, 190, 254, 382, 510, 766]
+    cls = np.searchsorted(bounds, hl, side="left")
+    assert list(c.hap_class_off) == [0] + np.cumsum(np.bincount(cls, minlength=7)).tolist()
+    assert [int(x) for x in c.hap_class_max] == [int(hl[cls == k].max()) if (cls == k).any() else 0 for k in range(7)]
+    rl = np.diff(pb.a["read_seq_off"])
+    assert c.n_read_classes == 2 and list(c.read_class_max) == [int(rl[rl <= 160].max()), int(rl.max())]
+    dev.launch()
+    torch.cuda.synchronize()
+    assert_same(dev.results(), _oracle.batch(p, pb, nthreads=8), pb)
