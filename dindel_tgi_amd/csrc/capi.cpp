@@ -50,9 +50,11 @@ int pick_K(int max_hap_len)
 
 int pick_Dt(int D)
 {
-    if (D == 6) return 6;
-    if (D == 11) return 11;
-    return 12; // generic build: candidates y > D are switched off with -inf constants
+    // every build switches candidates y > D off with -inf constants, so a smaller D runs on the next larger build
+    // (maxLengthDel 0..4 on the D=6 build: 2.4e11 -> 4.0e11 cells/s at configs[1]; 6..9 on the D=11 build)
+    if (D <= 6) return 6;
+    if (D <= 11) return 11;
+    return 12;
 }
 
 uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
