@@ -659,7 +659,7 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
             lds = (size_t)A.lds_shared_bytes + (size_t)waves * (groups < 4 ? groups + 1 : 4) * A.lds_wave_bytes;
         }
     }
-    const int64_t split = pick_split(b->n_haps, (avg_reads + groups - 1) / groups, waves, target_blocks);
+    const int64_t split = pick_split(hap_end - hap_begin, (avg_reads + groups - 1) / groups, waves, target_blocks);
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.n_split = (int32_t)split;
     A.item_begin = (int32_t)(hap_begin * split);
@@ -742,10 +742,12 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     int64_t target_blocks = 4096;
     if (const char *e = getenv("DD_TARGET_BLOCKS")) { const long v = atol(e); if (v >= 1) target_blocks = v; }   // A/B only
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
-    const int64_t split = pick_split(b->n_haps, avg_reads, waves, target_blocks);
-    A.n_split = (int32_t)split;
     if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
     if (lc && lc->hap_list) { hap_begin = lc->list_begin; hap_end = lc->list_end; }   // positions in the class list
+    // the split is chosen for the haplotypes THIS launch covers: a rare length class or a small window block must still
+    // spread over the chip
+    const int64_t split = pick_split(hap_end - hap_begin, avg_reads, waves, target_blocks);
+    A.n_split = (int32_t)split;
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.item_begin = (int32_t)(hap_begin * split);
     A.n_items = (int32_t)(hap_end * split);
