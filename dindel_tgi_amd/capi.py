@@ -108,7 +108,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
-           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -145,6 +145,7 @@ def load():
     lib.dd_build_symbol_lut.argtypes = [C.POINTER(dd_batch), C.POINTER(C.c_uint8)]
     lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
     lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_i32p, C.POINTER(dd_length_classes)]
+    lib.dd_plan_info.argtypes = [C.POINTER(dd_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]
     lib.dd_workspace_bytes.restype = C.c_size_t

@@ -771,6 +771,26 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     return DD_SUCCESS;
 }
 
+int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[8])
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!out) return fail(DD_ERR_INVALID, "null argument");
+    if (max_hap_len < 1 || max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype length outside [1,766]");
+    if (max_read_len < 1 || max_read_len > DD_MAX_READ_LEN) return fail(DD_ERR_UNSUPPORTED, "read length outside [1,1024]");
+    Plan pl;
+    ddk::KernelArgs A;
+    memset(&A, 0, sizeof(A));
+    if ((rc = make_plan(p, max_hap_len, max_read_len, n_qual, pl, A))) return rc;
+    const int waves = waves_for_reads(avg_reads, pl.waves);
+    out[0] = pl.K; out[1] = pl.Dt; out[2] = pl.gbt ? 1 : 0; out[3] = waves;
+    out[4] = (int32_t)pick_split(n_haps, avg_reads, waves, 4096);
+    out[5] = (int32_t)lds_layout(pl.K, pl.Dt, max_read_len, n_qual, waves, pl.gbt, A);
+    out[6] = (int32_t)((pl.scratch_bytes >> 10) & 0x7fffffff);
+    out[7] = pl.waves_per_cu;
+    return DD_SUCCESS;
+}
+
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (b && b->classes && b->hap_class_list) {

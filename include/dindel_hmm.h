@@ -291,6 +291,12 @@ int dd_map_pairs(const dd_batch *b, const double *ll_host, const double *prior_h
                  const int32_t *ncand_host, double *pair_sum_out, double *posterior_out, int32_t *pairs_out,
                  double *vals_out, int device);
 
+/* Launch plan the library would use for the main kernel on a batch with these maxima (no device needed):
+ * out = {K positions per lane, D build (6 / 11 / 12), 1 if back-pointers go to HBM scratch else 0, waves per workgroup,
+ *        read split of a haplotype, LDS bytes per workgroup, scratch bytes (low 31 bits, in KiB), waves per CU the plan expects}.
+ * avg_reads = reads per window, n_haps = haplotypes the launch covers. */
+int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[8]);
+
 /* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
 const char *dd_kernel_name(void);
 /* geometry of the last dd_launch_device on this host thread's library instance:

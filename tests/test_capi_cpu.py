@@ -165,3 +165,28 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert out[0] == out[1] and float(out[2]) == 5e-4
     # the ctypes mirror has the same struct size as the C compiler sees
     assert int(out[3]) == C.sizeof(capi.dd_batch)
+
+
+def test_launch_plan_rules(lib):
+    """dd_plan_info (no device needed) pins the launch heuristics the GPU sweeps settled (profiles/r01/plan_check.jsonl,
+    coverage_sweep.jsonl, batch_size_sweep.jsonl)."""
+    def plan(mld=5, hap=120, L=100, reads=200, haps=80000):
+        p = capi.params_cli_defaults(); p.maxLengthDel = mld
+        out = (C.c_int32 * 8)()
+        assert lib.dd_plan_info(C.byref(p), hap, L, 1, reads, haps, C.byref(out)) == 0, capi.last_error()
+        return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7])
+    # lane tiling by haplotype length: numS = Hs+2 <= 64 K
+    assert [plan(hap=h)["K"] for h in (62, 63, 126, 127, 190, 191, 254, 255, 382, 383, 510, 511, 766)] == [1, 2, 2, 3, 3, 4, 4, 6, 6, 8, 8, 12, 12]
+    # D routing: a smaller D runs on the next larger specialised build
+    assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
+    # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 3
+    assert [plan(L=l)["hbm"] for l in (36, 100, 110, 120, 150, 250, 1000)] == [0, 0, 0, 1, 1, 1, 1]
+    assert plan(hap=170)["hbm"] == 1 and plan(hap=170)["scratch_kib"] > 0 and plan()["scratch_kib"] == 0
+    assert plan()["waves"] == 4 and plan()["waves_cu"] == 12 and plan()["lds"] <= 160 * 1024
+    # workgroup size follows how well the windows' reads fill the waves
+    assert [plan(reads=r)["waves"] for r in (1, 2, 3, 5, 10, 20, 200)] == [1, 2, 3, 1, 2, 4, 4]
+    # read split: none for big batches; small batches split down to one round of reads per wave
+    assert plan(haps=80000)["split"] == 1 and plan(haps=8)["split"] == 50 and plan(haps=512)["split"] == 9
+    p = capi.params_cli_defaults()
+    out = (C.c_int32 * 8)()
+    assert lib.dd_plan_info(C.byref(p), 767, 100, 1, 200, 8, C.byref(out)) == capi.DD_ERR_UNSUPPORTED
