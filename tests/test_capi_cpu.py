@@ -190,3 +190,32 @@ def test_launch_plan_rules(lib):
     p = capi.params_cli_defaults()
     out = (C.c_int32 * 8)()
     assert lib.dd_plan_info(C.byref(p), 767, 100, 1, 200, 8, C.byref(out)) == capi.DD_ERR_UNSUPPORTED
+
+
+def test_length_classes_and_library_tables_on_the_host(lib):
+    """dd_build_length_classes and dd_build_library_tables are pure host helpers: checked here without a device."""
+    rng = np.random.default_rng(8)
+    wins = []
+    for hl, L in ((50, 36), (62, 100), (63, 100), (126, 161), (127, 160), (400, 300), (766, 1024)):
+        hap = "".join(rng.choice(list("ACGT"), hl))
+        wins.append(Window(1000, [hap, hap[:hl // 2] + hap[hl // 2 + 1:]], [ReadRec(hap[:min(L, hl)].ljust(L, "A"), [0.99] * L, 0.99, 1000)]))
+    probs = np.array([0.1, 0.2, 0.3, 0.4])
+    pb = pack(wins, libraries=[(probs, 0.3), (np.array([1.0]), 1.0)])
+    b = pb.ctypes_batch()
+    cls = capi.dd_length_classes()
+    lst = np.zeros(pb.n_haps, np.int32)
+    assert lib.dd_build_length_classes(C.byref(b), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    hl = np.diff(pb.a["hap_seq_off"])
+    c = np.searchsorted([62, 126, 190, 254, 382, 510, 766], hl, side="left")
+    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=7)).tolist()
+    assert sorted(lst.tolist()) == list(range(pb.n_haps))
+    for k in range(7):
+        seg = lst[cls.hap_class_off[k]:cls.hap_class_off[k + 1]]
+        assert (c[seg] == k).all() and (np.diff(seg) > 0).all()
+        assert cls.hap_class_max[k] == (int(hl[seg].max()) if len(seg) else 0)
+    assert cls.n_read_classes == 2 and list(cls.read_class_lo) == [1, 161] and list(cls.read_class_max) == [160, 1024]
+    lp = np.zeros(5); l95 = np.zeros(2)
+    assert lib.dd_build_library_tables(C.byref(b), lp.ctypes.data_as(capi.c_f64p), l95.ctypes.data_as(capi.c_f64p)) == 0
+    assert lp.tolist() == [math.log(x) for x in (0.1, 0.2, 0.3, 0.4, 1.0)] and l95.tolist() == [math.log(0.3), 0.0]
+    bad = pack(wins, libraries=[(np.array([0.5, 0.0]), 0.5)])
+    assert lib.dd_build_library_tables(C.byref(bad.ctypes_batch()), lp.ctypes.data_as(capi.c_f64p), l95.ctypes.data_as(capi.c_f64p)) == capi.DD_ERR_INVALID
