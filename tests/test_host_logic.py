@@ -1,7 +1,7 @@
 """Host logic: packing, slicing into rank shards, synthetic generator determinism."""
 import numpy as np
 
-from dindel_tgi_amd import synth
+from dindel_tgi_amd import capi, synth
 from dindel_tgi_amd.batch import ReadRec, Window, pack, pair_slices
 from dindel_tgi_amd.shard import window_block
 
@@ -51,3 +51,29 @@ def test_synth_is_deterministic_and_shaped():
     assert not np.array_equal(a.a["read_seq"], c.a["read_seq"])
     assert a.n_pairs == 3 * 8 * 200 and a.max_read_len == 100 and 117 <= a.max_hap_len <= 123
     assert set(bytes(a.a["hap_seq"])) <= set(b"ACGT")
+
+
+def test_slice_windows_carries_variants_flanks_and_mates():
+    """PackedBatch.slice_windows (how ranks shard a job) must carry every optional array: haplotype variants, flank
+    intervals, mate / library inputs.  Oracle results of the slices, concatenated, equal those of the whole batch."""
+    from tests import _oracle
+    from tests.test_gpu_fuzz import make_windows
+    from tests.test_insert_prior import library
+    rng = np.random.default_rng(21)
+    ws = make_windows(rng, 9, 70, 50, min_hap=5, with_vars=True)
+    libs = [library(rng, 200, 80), library(rng, 50, 20)]
+    for w in ws:
+        for r in w.reads:
+            r.paired = True; r.mate_same_tid = bool(rng.random() < 0.8); r.mate_reverse = bool(rng.random() < 0.5)
+            r.mate_pos = int(r.start % 2 ** 30) + int(rng.integers(-100, 100)); r.mate_len = int(rng.choice([-1, 50])); r.lib = int(rng.integers(0, 2))
+    pb = pack(ws, libraries=libs)
+    p = capi.params_cli_defaults()
+    p.mapUnmappedReads = 1
+    full = _oracle.batch(p, pb, nthreads=4)
+    cuts = [0, 2, 3, 7, 9]
+    parts = [_oracle.batch(p, pb.slice_windows(a, b), nthreads=2) for a, b in zip(cuts[:-1], cuts[1:])]
+    sl = [pb.slice_windows(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    for k, n in (("ll", "n_pairs"), ("hpos", "hpos_len"), ("var_covered", "var_cov_len"), ("var_fcov", "var_cov_len"), ("onHap", "n_reads")):
+        cat = np.concatenate([r[k][:getattr(s, n)] for r, s in zip(parts, sl)])
+        assert np.array_equal(cat, full[k][:getattr(pb, n)]), k
+    assert sum(s.var_cov_len for s in sl) == pb.var_cov_len > 0
