@@ -14,10 +14,12 @@
 //     sweep of straight-line fp64 add / compare / select code;
 //   * neighbour states (the <= D = maxLengthDel+1 jump candidates) come from a wave-private LDS row;
 //     single buffer, no barrier: DS operations of one wave execute in order;
-//   * back-pointers are one byte per (read base, position) in wave-private LDS, the traceback walks
-//     them there, and hpos[] / QC counters are produced lane-parallel over read bases;
+//   * back-pointers are 4 (5 when D > 7) bits per (read base, position), packed per lane into one word of
+//     wave-private LDS — or of a per-wave HBM scratch tile in the GBT builds; the scalarised traceback walks
+//     them, and hpos[] / QC counters are produced lane-parallel over read bases;
 //   * no transcendental is evaluated on the device: every log() the reference takes is tabulated on
-//     the host with libm (tables.cpp) so results cannot differ from glibc's.
+//     the host with libm (dd_build_tables, capi.cpp) so results cannot differ from glibc's;
+//   * bases are compared as symbol ids from a 256-entry table (dd_build_symbol_lut): any byte, as in the reference.
 //
 // Arithmetic: fp64, every sum in the reference's written term order (fp64 + is not associative and
 // updateMax has a 1e-10 hysteresis, ObservationModelFB.cpp:877-888).  No MFMA: this is a max-plus
