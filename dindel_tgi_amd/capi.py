@@ -21,6 +21,9 @@ c_f64p = C.POINTER(C.c_double)
 DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 2 * 256 + 64
 DD_READ_UNMAPPED, DD_READ_PAIRED, DD_READ_MATE_UNMAPPED, DD_READ_MATE_REVERSE, DD_READ_MATE_SAME_TID = 1, 2, 4, 8, 16
 
+ABI_VERSION = 9            # DD_ABI_VERSION of include/dindel_hmm.h
+DD_HPOS_INS, DD_HPOS_LO, DD_HPOS_RO, DD_HPOS_INS_KEY0 = -1, -3, -4, -16
+
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
 DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS = 0, 1, 2, 3
 
@@ -175,3 +178,12 @@ def last_launch():
 
 def last_error():
     return load().dd_last_error().decode()
+
+
+def hpos_reference_codes(hpos):
+    """hpos as the library writes it (inserted bases carry their key: DD_HPOS_INS_KEY0 - pos) -> the reference's
+    MLAlignment::hpos codes (every inserted base -1)."""
+    import numpy as np
+    h = np.asarray(hpos).copy()
+    h[h < DD_HPOS_INS_KEY0] = DD_HPOS_INS
+    return h

@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int xm = s % numS;
                 int hp;
                 if (xm > 0 && xm <= hlen) {
-                    if (s >= numS) hp = DD_HPOS_INS;
+                    if (s >= numS) hp = DD_HPOS_INS_KEY0 - xm;     // inserted base, carrying its key (pos = lhp, :556-566, :608)
                     else { hp = s - 1; firstB = hp < firstB ? hp : firstB; lastB = hp > lastB ? hp : lastB; }
                 } else hp = (xm == 0) ? DD_HPOS_LO : DD_HPOS_RO;
                 if (hp_out) hp_out[b] = (int16_t)hp;

@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 if (x == 0) hp = DD_HPOS_LO;
                 else if (x == RO) hp = DD_HPOS_RO;
                 else if (ins) {
-                    hp = DD_HPOS_INS;
+                    hp = DD_HPOS_INS_KEY0 - x;                                  // inserted base, carrying its key (pos = x, :1380)
                     pIndel = (b == 0 || ms[b - 1] < numS);                      // start of an insertion run (:1379-1394)
                 } else {
                     hp = x - 1;

@@ -60,8 +60,10 @@ static dd_params to_abi(const ObservationModelParameters &o)
 }
 
 // Rebuilds what reportVariants derives from mapState (reference ObservationModelFB.cpp:1351-1475), from
-// hpos: >=0 haplotype index, -1 INS, -3 LO, -4 RO.  An insertion run is keyed at the haplotype position of
-// the inserted state; hpos does not carry it, but it equals (next on-haplotype base) or (previous + 1).
+// hpos: >=0 haplotype index, -3 LO, -4 RO, inserted base = DD_HPOS_INS_KEY0 - pos as the library writes it (pos = the x of
+// the inserted state numS+x, which keys ml.indels, :1380).  A bare MLAlignment::INS (-1: an array in the reference's own
+// coding) is accepted too; its key is then taken from the neighbouring entries — (previous on-haplotype base)+1 or the
+// next on-haplotype base — which is what the model's transitions imply whenever the run has such a neighbour.
 void LikelihoodEngine::rebuildAlignment(const Haplotype &hap, const Read &read, const int16_t *hp,
                                         const ObservationModelParameters &p, MLAlignment &ml)
 {
@@ -71,19 +73,20 @@ void LikelihoodEngine::rebuildAlignment(const Haplotype &hap, const Read &read, 
     ml.hpos.assign(L, 0);
     ml.firstBase = -1; ml.lastBase = -1;
     ml.nBQT = 0; ml.nmmBQT = 0; ml.mLogBQ = 0.0; ml.nMMRight = 0; ml.nMMLeft = 0; ml.numIndels = 0; ml.numMismatch = 0;
-    for (int b = 0; b < L; b++) ml.hpos[b] = hp[b];
+    for (int b = 0; b < L; b++) ml.hpos[b] = DD_HPOS_IS_INS(hp[b]) ? int(MLAlignment::INS) : int(hp[b]);
     int b = 0;
     while (b < L) {
         const int h = hp[b];
-        if (h == MLAlignment::INS) {
+        if (DD_HPOS_IS_INS(h)) {
             // inserted state numS+x: x-1 is the last haplotype base the read consumed before the run (an insertion
             // is entered from "on base x", ObservationModelFB.cpp:1823-1826 / 1746-1749), so pos = x (:1380)
             int rpos = b, len = 0;
-            while (b < L && hp[b] == MLAlignment::INS) { b++; len++; }
+            while (b < L && DD_HPOS_IS_INS(hp[b])) { b++; len++; }
             int pos;
-            if (rpos > 0 && hp[rpos - 1] >= 0) pos = hp[rpos - 1] + 1;
+            if (h != MLAlignment::INS) pos = DD_HPOS_INS_POS(h);  // the key the device recorded
+            else if (rpos > 0 && hp[rpos - 1] >= 0) pos = hp[rpos - 1] + 1;
             else if (b < L && hp[b] >= 0) pos = hp[b];           // run starts the read: next on-haplotype base
-            else pos = (rpos > 0 && hp[rpos - 1] == MLAlignment::LO) ? 1 : Hs;   // degenerate: only off-haplotype neighbours
+            else pos = Hs;                                       // bare code, run followed by RO: inserted at the last base
             std::string seq = read.seq.seq.substr(rpos, len);
             ml.indels[pos] = AlignedVariant(std::string("+").append(seq), pos, pos, rpos, b - 1);
             ml.numIndels++;
@@ -140,17 +143,18 @@ void LikelihoodEngine::rebuildAlignmentFaster(const Haplotype &hap, const Read &
     const int L = int(read.size()), Hs = int(hap.size());
     ml.align = std::string(Hs, 'R');
     ml.indels.clear(); ml.snps.clear(); ml.hapIndelCovered.clear(); ml.hapSNPCovered.clear();
-    ml.hpos.assign(hp, hp + L);
+    ml.hpos.assign(size_t(L), 0);
+    for (int i = 0; i < L; i++) ml.hpos[size_t(i)] = DD_HPOS_IS_INS(hp[i]) ? int(MLAlignment::INS) : int(hp[i]);
     ml.firstBase = -1; ml.lastBase = -1;
-    int lhp = 1;                                       // Faster.cpp:553
+    int lhp = 1;                                       // Faster.cpp:553 (only used for a bare INS code)
     int b = 0;
     while (b < L) {
         const int h = hp[b];
-        if (h == MLAlignment::INS) {                   // Faster.cpp:606-621
+        if (DD_HPOS_IS_INS(h)) {                       // Faster.cpp:606-621
             const int rpos = b;
             int len = 0;
-            while (b < L && hp[b] == MLAlignment::INS) { b++; len++; }
-            const int pos = lhp;
+            while (b < L && DD_HPOS_IS_INS(hp[b])) { b++; len++; }
+            const int pos = (h != MLAlignment::INS) ? DD_HPOS_INS_POS(h) : lhp;   // the key the device recorded (lhp of :556-566)
             ml.indels[pos] = AlignedVariant(std::string("+").append(read.seq.seq.substr(rpos, len)), pos, pos, rpos, b - 1);
             continue;
         }

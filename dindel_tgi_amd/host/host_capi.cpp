@@ -62,6 +62,8 @@ int ddh_rebuild_json(const char *hap, const char *read, const double *qual, cons
                      const double *pd, const int *pi, const int *hap_indels /* n x {key,startRead,endRead} */, int n_hap_indels,
                      char *out, int cap)
 {
+    const bool faster = (n_hap_indels & 0x10000) != 0;       // bit 16: ObservationModelS::reportVariants instead
+    n_hap_indels &= 0xffff;
     try {
         Haplotype H((std::string(hap)));
         for (int i = 0; i < n_hap_indels; i++)
@@ -70,7 +72,8 @@ int ddh_rebuild_json(const char *hap, const char *read, const double *qual, cons
         R.seq.seq = read;
         R.qual.assign(qual, qual + L);
         MLAlignment ml;
-        LikelihoodEngine::rebuildAlignment(H, R, hpos, make_params(pd, pi), ml);
+        if (faster) LikelihoodEngine::rebuildAlignmentFaster(H, R, hpos, make_params(pd, pi), ml);
+        else LikelihoodEngine::rebuildAlignment(H, R, hpos, make_params(pd, pi), ml);
         std::ostringstream os;
         json_ml(os, ml);
         return emit(os.str(), out, cap);

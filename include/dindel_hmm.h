@@ -33,13 +33,22 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 8
+#define DD_ABI_VERSION 9
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
 #define DD_HPOS_DEL (-2)
 #define DD_HPOS_LO  (-3)
 #define DD_HPOS_RO  (-4)
+/* hpos[] AS WRITTEN BY THIS LIBRARY carries, for an inserted read base, the haplotype position the reference keys the
+ * insertion at (`pos`, ObservationModelFB.cpp:1380 / Faster.cpp:608 — the x of the inserted state numS+x) instead of the
+ * bare MLAlignment::INS: the value is DD_HPOS_INS_KEY0 - pos (pos >= 1, so <= -17).  MLAlignment::hpos only says "-1", and
+ * the key cannot always be recovered from the neighbouring entries (a read that is inserted as a whole; in the --faster model
+ * an insertion after bases parked on the last haplotype base), yet ml.indels is keyed by it.  A consumer that wants the
+ * reference's array maps DD_HPOS_IS_INS(v) to DD_HPOS_INS (the C++ adapter does). */
+#define DD_HPOS_INS_KEY0    (-16)
+#define DD_HPOS_IS_INS(v)   ((v) == DD_HPOS_INS || (v) < DD_HPOS_INS_KEY0)
+#define DD_HPOS_INS_POS(v)  (DD_HPOS_INS_KEY0 - (v))
 
 /* return codes of the entry points */
 #define DD_SUCCESS            0
@@ -149,7 +158,8 @@ typedef struct dd_result {
     uint8_t *offHap, *offHapHMQ;
     int16_t *numIndels, *numMismatch, *nBQT, *nmmBQT, *nMMLeft, *nMMRight, *firstBase, *lastBase;
     int16_t *hpos;        /* L entries per pair, at  hpos_off(w) + h*SL_w + (read_seq_off[r]-read_seq_off[r0(w)]),
-                             SL_w = total read bases of window w;  >=0 hap index, -1 INS, -3 LO, -4 RO */
+                             SL_w = total read bases of window w;  >=0 hap index, -3 LO, -4 RO,
+                             inserted base: DD_HPOS_INS_KEY0 - pos (see DD_HPOS_INS_POS) */
     uint8_t *var_covered; /* per (pair, variant of that hap): hapIndelCovered / hapSNPCovered        */
     int32_t *status;      /* DD_PAIR_*                                                               */
     uint8_t *onHap;       /* [n_reads] 1 iff any hap of the window has !offHapHMQ (DInDel.cpp:1720)  */

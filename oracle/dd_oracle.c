@@ -272,6 +272,11 @@ int ddo_pair(const char *hap, int Hs, const char *readseq, const double *qual, i
     return ddo_pair_mate(hap, Hs, readseq, qual, L, mapQual, readStartU32, hapStart, unmapped, P, NULL, out, hpos);
 }
 
+/* Where the batch writer wants the key (`pos`, :1380 / Faster.cpp:608) of every inserted read base: the product's hpos
+ * carries it (DD_HPOS_INS_KEY0 - pos, include/dindel_hmm.h), the reference's MLAlignment::hpos — which the per-pair entry
+ * points return — only says INS.  NULL outside ddo_batch*. */
+static __thread int *g_ins_key = NULL;
+
 static int pair_impl(int plain_fbmax, const char *hap, int Hs, const char *readseq, const double *qual, int L,
                      double mapQual, uint32_t readStartU32, uint32_t hapStart, int unmapped,
                      const dd_params *P, const ddo_mate *mate, ddo_out *out, int *hpos);
@@ -482,6 +487,7 @@ static int pair_impl(int plain_fbmax, const char *hap, int Hs, const char *reads
                 int rpos = b;
                 while (b < L && m->mapState[b] >= numS) {
                     hpos[b] = DD_HPOS_INS;
+                    if (g_ins_key) g_ins_key[b] = pos;
                     b++;
                     len++;
                 }
@@ -582,6 +588,7 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
         }
         double *q = (double *)malloc(sizeof(double) * (size_t)(maxL + 1));
         int *hp = (int *)malloc(sizeof(int) * (size_t)(maxL + 1));
+        int *ikey = (int *)malloc(sizeof(int) * (size_t)(maxL + 1));
         int64_t vcbase = vc_off[w];
         if (R->onHap) for (r = r0; r < r1; r++) R->onHap[r] = 0;
         for (h = h0; h < h1; h++) {
@@ -595,6 +602,7 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
                 ddo_out o;
                 int64_t p = pair_off[w] + (int64_t)(h - h0) * Rn + (r - r0);
                 for (i = 0; i < L; i++) q[i] = B->qual_table[B->read_qidx[so + i]];
+                g_ins_key = ikey;
                 if (model == 0) {
                     ddo_mate mt, *pm = NULL;
                     if (P->mapUnmappedReads && B->read_mate_pos) {
@@ -614,6 +622,7 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
                                   B->win_hap_start[w], P, &o, hp);
                     if (o.status != DD_PAIR_OK) { o.offHapHMQ = 1; o.status = (o.status == DD_PAIR_HAPSIZE) ? DD_PAIR_HAPSIZE : DD_PAIR_NAN; }
                 }
+                g_ins_key = NULL;
                 const int bad = (o.status == DD_PAIR_HAPSIZE) || (model == 1 && o.status != DD_PAIR_OK);
                 R->ll[p] = o.ll;
                 R->status[p] = o.status;
@@ -632,7 +641,7 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
                 if (R->lastBase) R->lastBase[p] = (int16_t)o.lastBase;
                 if (R->hpos && !bad) {
                     int16_t *dst = R->hpos + hpos_off[w] + (int64_t)(h - h0) * SL + (so - B->read_seq_off[r0]);
-                    for (i = 0; i < L; i++) dst[i] = (int16_t)hp[i];
+                    for (i = 0; i < L; i++) dst[i] = (int16_t)(hp[i] == DD_HPOS_INS ? DD_HPOS_INS_KEY0 - ikey[i] : hp[i]);   /* the product's encoding */
                 }
                 if (R->var_covered && nv > 0) {
                     /* AlignedVariant::isCovered — Variant.hpp:125-128; ObservationModelFB.cpp:1465-1472 */
@@ -684,6 +693,7 @@ static int batch_impl(const dd_params *P, const dd_batch *B, dd_result *R, int n
         }
         free(q);
         free(hp);
+        free(ikey);
     }
     free(pair_off); free(hpos_off); free(vc_off);
     return 0;
@@ -948,7 +958,7 @@ int ddo_pair_fast(const char *hap, int hlen, const char *readseq, const double *
             if ((st % numS) > 0 && (st % numS) <= hlen) {
                 if (st >= numS) {
                     int pos = (st % numS) - 1 + 1, len = 0, rpos = b;
-                    while (b < rlen && mapState[b] >= numS) { hpos[b] = DD_HPOS_INS; b++; len++; }
+                    while (b < rlen && mapState[b] >= numS) { hpos[b] = DD_HPOS_INS; if (g_ins_key) g_ins_key[b] = pos; b++; len++; }
                     if (out->n_indel < DDO_MAX_VAR) { out->indel_pos[out->n_indel] = pos; out->indel_len[out->n_indel] = len; out->indel_rpos[out->n_indel] = rpos; out->n_indel++; }
                     b--;
                 } else {

@@ -6,7 +6,7 @@
 extern "C" {
 #endif
 
-#define DDO_MAX_VAR 64
+#define DDO_MAX_VAR 1056   /* > DD_MAX_READ_LEN: a read cannot show more variants than it has bases */
 
 typedef struct ddo_out {
     double ll, llOn, llOff, mLogBQ;

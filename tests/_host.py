@@ -31,7 +31,7 @@ def _params(p):
     return pd, pi
 
 
-def rebuild(hap, read, qual, hpos, params, hap_indels=()):
+def rebuild(hap, read, qual, hpos, params, hap_indels=(), faster=False):
     lib = load()
     L = len(read)
     q = np.ascontiguousarray(np.broadcast_to(np.asarray(qual, np.float64), (L,)))
@@ -41,7 +41,7 @@ def rebuild(hap, read, qual, hpos, params, hap_indels=()):
     out = C.create_string_buffer(1 << 20)
     n = lib.ddh_rebuild_json(hap.encode(), read.encode(), q.ctypes.data_as(capi.c_f64p),
                              hp.ctypes.data_as(C.POINTER(C.c_short)), L, pd, pi,
-                             hv.ctypes.data_as(capi.c_i32p), len(hap_indels), out, len(out))
+                             hv.ctypes.data_as(capi.c_i32p), len(hap_indels) | (0x10000 if faster else 0), out, len(out))
     assert n > 0
     return json.loads(out.value.decode())
 

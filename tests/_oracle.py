@@ -11,7 +11,7 @@ from dindel_tgi_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.environ.get("DD_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libdd_oracle.so")
-MAXV = 64
+MAXV = 1056
 
 
 class ddo_out(C.Structure):
@@ -99,3 +99,55 @@ def batch(params, pb, nthreads=1, first_window=0, n_win=-1, faster=False):
     rc = fn(C.byref(params), C.byref(b), C.byref(res), nthreads, first_window, n_win)
     assert rc == 0
     return arrs
+
+
+def keyed_hpos(o, hpos):
+    """hpos of a per-pair call (the reference's codes: every inserted base -1) -> the product's coding, in which an
+    inserted base carries the key of its insertion (DD_HPOS_INS_KEY0 - pos, include/dindel_hmm.h)."""
+    out = list(hpos)
+    assert o.n_indel < MAXV
+    for i in range(o.n_indel):
+        if o.indel_len[i] > 0:
+            for b in range(o.indel_rpos[i], o.indel_rpos[i] + o.indel_len[i]):
+                assert out[b] == capi.DD_HPOS_INS
+                out[b] = capi.DD_HPOS_INS_KEY0 - o.indel_pos[i]
+    assert capi.DD_HPOS_INS not in out
+    return out
+
+
+def expected_variants(o, hap, read):
+    """ml.indels / ml.snps as reportVariants builds them (ObservationModelFB.cpp:1375-1453, Faster.cpp:606-661) from the
+    oracle's variant lists: ({pos: [string, startHap, endHap, startRead, endRead]}, {pos: string}); std::map semantics, a
+    later variant at the same key replaces the earlier one."""
+    assert o.n_indel < MAXV and o.n_snp < MAXV
+    indels, snps = {}, {}
+    for i in range(o.n_indel):
+        pos, ln, rp = o.indel_pos[i], o.indel_len[i], o.indel_rpos[i]
+        if ln > 0:
+            indels[pos] = ["+" + read[rp:rp + ln], pos, pos, rp, rp + ln - 1]
+        else:
+            indels[pos] = ["-" + hap[pos:pos - ln], pos, pos - ln - 1, rp, rp + 1]
+    for i in range(o.n_snp):
+        snps[o.snp_pos[i]] = hap[o.snp_pos[i]] + "=>" + read[o.snp_rpos[i]]
+    return indels, snps
+
+
+def assert_record_variants(ml, o, hap, read, ctx=None):
+    """The indel / SNP maps of a JSON MLAlignment record (tests/_host.py) against the oracle: keys, strings, coordinates."""
+    indels, snps = expected_variants(o, hap, read)
+    assert {i[0]: i[1:] for i in ml["indels"]} == indels, (ctx, ml["indels"], indels)
+    assert {s[0]: s[1] for s in ml["snps"]} == snps, (ctx, ml["snps"], snps)
+
+
+def expected_align(o, hap, read):
+    """ml.align (ObservationModelFB.cpp:1355, :1428, :1443): 'R' per haplotype base, the read base where a SNP sits, 'D'
+    over deleted bases (clipped to the haplotype: a deletion that reaches RO would write past the string's end)."""
+    al = ["R"] * len(hap)
+    ev = [(o.snp_rpos[i], 0, i) for i in range(o.n_snp)] + [(o.indel_rpos[i], 1, i) for i in range(o.n_indel) if o.indel_len[i] < 0]
+    for _rp, kind, i in sorted(ev):          # in read order; within one base the SNP is written before the deletion
+        if kind == 0:
+            al[o.snp_pos[i]] = read[o.snp_rpos[i]]
+        else:
+            for y in range(o.indel_pos[i], min(o.indel_pos[i] - o.indel_len[i], len(hap))):
+                al[y] = "D"
+    return "".join(al)

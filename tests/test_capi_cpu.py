@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(capi.EXPORTS), (names, capi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.dd_abi_version() == 8
+    assert lib.dd_abi_version() == capi.ABI_VERSION
     assert lib.dd_kernel_name().decode() == "dd_hmm_kernel"
 
 

@@ -62,11 +62,15 @@ def test_traceback_is_a_monotone_path(full):
     assert bool(((fb == first) | none).all()) and bool(((lb == last) | none).all())
     assert bool((fb[none] == -1).all())
     # numIndels = insertion runs + deletions, recomputed from hpos alone
-    ins = hp == -1
+    hs = torch.from_numpy(np.repeat(np.diff(pb.a["hap_seq_off"]).astype(np.int32), 200)).to(hp.device)
+    ins = hp < capi.DD_HPOS_INS_KEY0                                           # inserted bases: DD_HPOS_INS_KEY0 - key
+    # the key is the x of the inserted state: one past the last on-haplotype base before the run, if there is one
+    keyv = capi.DD_HPOS_INS_KEY0 - hp
+    assert bool((~(ins & (prev >= 0)) | (keyv == prev + 1)).all())
+    assert bool((~ins | ((keyv >= 1) & (keyv <= hs[:, None]))).all())
     prev_ins = torch.cat([torch.zeros_like(ins[:, :1]), ins[:, :-1]], dim=1)
     n_ins = (ins & ~prev_ins).sum(dim=1)
     nxt = torch.cat([hp[:, 1:], torch.full_like(hp[:, :1], -1)], dim=1)
-    hs = torch.from_numpy(np.repeat(np.diff(pb.a["hap_seq_off"]).astype(np.int32), 200)).to(hp.device)
     nxt_state = torch.where(nxt >= 0, nxt, torch.where(nxt == -4, hs[:, None], torch.full_like(nxt, -(1 << 20))))
     last_col = torch.arange(100, device=hp.device)[None, :] == 99
     n_del = (on & ~last_col & (nxt_state - hp > 1)).sum(dim=1)

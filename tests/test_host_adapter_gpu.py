@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from dindel_tgi_amd import capi
+from dindel_tgi_amd.batch import ReadRec, Window
 from tests import _host, _oracle
 
 pytestmark = pytest.mark.gpu
@@ -52,6 +53,7 @@ def test_engine_window_matches_oracle_and_onhap():
             assert ml["ll"] == o.ll and ml["llOn"] == o.llOn and ml["llOff"] == o.llOff
             assert ml["hpos"] == hpos
             assert (ml["offHap"], ml["offHapHMQ"]) == (o.offHap, o.offHapHMQ)
+            _oracle.assert_record_variants(ml, o, hap, read, (h, r))
             if not o.offHapHMQ:
                 on[r] = 1
     assert res["onHap"] == on
@@ -160,11 +162,7 @@ def test_engine_faster_window_matches_oracle():
                 assert ml["ll"] == o.ll and ml["hpos"] == hpos
                 assert (ml["firstBase"], ml["lastBase"]) == (o.firstBase, o.lastBase)
                 assert (ml["offHap"], ml["offHapHMQ"], ml["numIndels"], ml["nBQT"]) == (0, 0, 0, 0)
-                want = sorted((o.indel_pos[i], o.indel_len[i], o.indel_rpos[i]) for i in range(o.n_indel))
-                got = sorted((i[0], (len(i[1]) - 1) * (1 if i[1][0] == "+" else -1), i[4]) for i in ml["indels"])
-                # several events at one haplotype position overwrite each other in the reference's map: compare by position
-                assert {w[0]: w for w in want} == {g[0]: g for g in got}
-                assert sorted(s[0] for s in ml["snps"]) == sorted(set(o.snp_pos[i] for i in range(o.n_snp)))
+                _oracle.assert_record_variants(ml, o, hap, read, (h, r))   # keys, strings, haplotype and read coordinates
                 n_indel += o.n_indel
         assert n_indel > 0
 
@@ -176,9 +174,10 @@ def test_engine_faster_throws_reference_strings():
         {"throw": "HapHash string too short"}
 
 
-def test_engine_fast_unpack_equals_full_rebuild():
-    """runBatch fills gap-free, mismatch-free pairs from the device's counters without the per-base walk: every record
-    must equal what rebuildAlignment (ObservationModelFBMax::reportVariants restated) derives from the same hpos."""
+def test_engine_fast_unpack_equals_oracle():
+    """runBatch fills gap-free, mismatch-free pairs from the device's counters without the per-base walk: every record,
+    whichever way it was filled, must equal the oracle's reportVariants (ObservationModelFB.cpp:1351-1475) — counters,
+    hpos, and the keys / strings / coordinates of ml.indels and ml.snps."""
     rng = np.random.default_rng(11)
     ref = "".join(rng.choice(list("ACGT"), 110))
     haps = [ref, ref[:50] + ref[53:], ref[:60] + "TTG" + ref[60:], ref[:30] + "N" + ref[31:]]
@@ -198,11 +197,12 @@ def test_engine_fast_unpack_equals_full_rebuild():
     for h, hap in enumerate(haps):
         for r, read in enumerate(reads):
             ml = res["liks"][h][r]
-            full = _host.rebuild(hap, read, quals[r], ml["hpos"], p)
-            for k in ("numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft", "nMMRight", "firstBase", "lastBase", "align",
-                      "indels", "snps", "hpos"):
-                assert ml[k] == full[k], (h, r, k)
-            assert ml["mLogBQ"] == pytest.approx(full["mLogBQ"], rel=1e-15, abs=0)
+            o, hpos = _oracle.pair(hap, read, quals[r], mapq[r], int(pos[r]), 1000, p)
+            for k in ("numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft", "nMMRight", "firstBase", "lastBase", "mLogBQ"):
+                assert ml[k] == getattr(o, k), (h, r, k)
+            assert ml["hpos"] == hpos
+            _oracle.assert_record_variants(ml, o, hap, read, (h, r))
+            assert ml["align"] == _oracle.expected_align(o, hap, read)
             n_plain += (not ml["indels"] and not ml["snps"])
     assert 20 < n_plain < len(haps) * len(reads)
 
@@ -210,13 +210,19 @@ def test_engine_fast_unpack_equals_full_rebuild():
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_engine_random_windows_both_models(seed):
     """Adversarial windows (tests/test_gpu_fuzz.make_windows: tiny alphabets, N / IUPAC bytes, indel-carrying and junk reads,
-    reads hanging off either end) through LikelihoodEngine: every record equals the oracle's values and, for the main
-    model, what rebuildAlignment derives from the same hpos (this exercises the counter + memcmp fast path of the unpack)."""
+    reads hanging off either end, 1-3-bp reads, reads that are inserted as a whole) through LikelihoodEngine: every record
+    equals the oracle's values, including the keys, strings and coordinates of ml.indels / ml.snps of both models."""
     from tests.test_gpu_fuzz import make_windows
     rng = np.random.default_rng(7000 + seed)
     p = capi.params_cli_defaults() if seed % 2 else capi.params_struct_defaults()
-    n_pairs = 0
-    for w in make_windows(rng, 6, 90, 70, min_hap=p.maxLengthDel):
+    n_pairs = n_whole_ins = 0
+    ws = make_windows(rng, 6, 90, 70, min_hap=p.maxLengthDel)
+    # the advisor's case (a read that is inserted as a whole: its key is the join's state, not a neighbour's) and 1-3-bp reads
+    q1 = [0.9999]
+    ws.append(Window(1000, ["A" * 30, "A" * 12 + "C" + "A" * 17], [ReadRec("C", q1, 0.9999, 1010), ReadRec("G", q1, 0.99, 1000),
+                                                                   ReadRec("CG", q1 * 2, 0.9999, 1005), ReadRec("TTT", q1 * 3, 0.9999, 1020),
+                                                                   ReadRec("GGGGGGGG", q1 * 8, 0.9999, 1008)]))
+    for w in ws:
         reads = [r.seq for r in w.reads]
         quals = [list(r.qual) for r in w.reads]
         mapq = [r.mapQual for r in w.reads]
@@ -232,14 +238,15 @@ def test_engine_random_windows_both_models(seed):
                 assert (ml["numIndels"], ml["numMismatch"], ml["nBQT"], ml["nmmBQT"], ml["nMMLeft"], ml["nMMRight"]) == \
                     (o.numIndels, o.numMismatch, o.nBQT, o.nmmBQT, o.nMMLeft, o.nMMRight)
                 assert (ml["firstBase"], ml["lastBase"], ml["offHap"], ml["offHapHMQ"]) == (o.firstBase, o.lastBase, o.offHap, o.offHapHMQ)
-                full = _host.rebuild(hap, rd.seq, rd.qual, hpos, p)
-                for k in ("align", "indels", "snps"):
-                    assert ml[k] == full[k], (h, r, k)
+                _oracle.assert_record_variants(ml, o, hap, rd.seq, (seed, h, r))
+                assert ml["align"] == _oracle.expected_align(o, hap, rd.seq)
+                n_whole_ins += bool(hpos) and all(x == capi.DD_HPOS_INS for x in hpos)
                 if "liks" in resf:
                     f, fh = _oracle.pair_fast(hap, rd.seq, rd.qual, rd.mapQual, rd.start, w.hap_start, p)
                     mf = resf["liks"][h][r]
                     assert mf["ll"] == f.ll and mf["hpos"] == fh and (mf["firstBase"], mf["lastBase"]) == (f.firstBase, f.lastBase)
+                    _oracle.assert_record_variants(mf, f, hap, rd.seq, ("faster", seed, h, r))
                 n_pairs += 1
         if any(len(r.seq) < 4 for r in w.reads):
             assert resf == {"throw": "HapHash string too short"}, (str(resf)[:300], [len(r.seq) for r in w.reads], [len(h) for h in w.haps])
-    assert n_pairs > 15
+    assert n_pairs > 15 and n_whole_ins > 0

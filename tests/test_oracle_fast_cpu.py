@@ -28,7 +28,9 @@ def test_batch_driver_equals_pair_function():
                 if o.status == 0:
                     n_ok += 1
                     assert res["ll"][pair] == o.ll
-                    assert res["hpos"][hp + off:hp + off + len(r.seq)].tolist() == hpos
+                    got = res["hpos"][hp + off:hp + off + len(r.seq)]
+                    assert got.tolist() == _oracle.keyed_hpos(o, hpos)            # inserted bases carry their key
+                    assert capi.hpos_reference_codes(got).tolist() == hpos       # ... and map back to MLAlignment's codes
                     assert (res["firstBase"][pair], res["lastBase"][pair]) == (o.firstBase, o.lastBase)
                     assert res["offHap"][pair] == 0 and res["offHapHMQ"][pair] == 0
                     on = [x for x in hpos if x >= 0]
