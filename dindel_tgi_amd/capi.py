@@ -25,7 +25,8 @@ ABI_VERSION = 9            # DD_ABI_VERSION of include/dindel_hmm.h
 DD_HPOS_INS, DD_HPOS_LO, DD_HPOS_RO, DD_HPOS_INS_KEY0 = -1, -3, -4, -16
 
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
-DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS = 0, 1, 2, 3
+DD_PAIR_OK, DD_PAIR_HAPSIZE, DD_PAIR_NAN, DD_PAIR_LLPOS, DD_PAIR_UNSUPPORTED = 0, 1, 2, 3, 4
+DD_MAX_HAP_LEN, DD_MAX_READ_LEN = 766, 1024
 
 
 class dd_params(C.Structure):
@@ -97,7 +98,7 @@ class dd_device_batch(C.Structure):
                 ("n_qual", C.c_int32), ("n_mapq", C.c_int32), ("hap_var_flank", C.c_void_p), ("sym_lut", C.c_void_p),
                 ("read_mate_pos", C.c_void_p), ("read_mate_len", C.c_void_p), ("read_lib", C.c_void_p),
                 ("lib_off", C.c_void_p), ("lib_logprob", C.c_void_p), ("lib_log95", C.c_void_p),
-                ("hap_class_list", C.c_void_p), ("classes", C.c_void_p)]
+                ("hap_class_list", C.c_void_p), ("classes", C.c_void_p), ("win_skip", C.c_void_p)]
 
 
 class dd_length_classes(C.Structure):
@@ -110,7 +111,7 @@ class dd_device_result(C.Structure):
     _fields_ = [(n, C.c_void_p) for n, _ in RESULT_FIELDS]
 
 
-EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets",
+EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets", "dd_screen_windows",
            "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
@@ -147,7 +148,8 @@ def load():
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_symbol_lut.argtypes = [C.POINTER(dd_batch), C.POINTER(C.c_uint8)]
     lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
-    lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_i32p, C.POINTER(dd_length_classes)]
+    lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_u8p, c_i32p, C.POINTER(dd_length_classes)]
+    lib.dd_screen_windows.argtypes = [C.POINTER(dd_batch), c_u8p, C.POINTER(C.c_int32 * 2)]
     lib.dd_plan_info.argtypes = [C.POINTER(dd_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -214,7 +215,17 @@ struct DeviceCtx {
         return DD_SUCCESS;
     }
 };
-struct CtxHolder { DeviceCtx c; ~CtxHolder() { /* process/thread exit: the HIP runtime may already be gone; leak */ } };
+// A host thread that ends gives its arena, pinned mirror and streams back (short-lived worker threads would otherwise
+// leak them without bound).  Once exit() has begun the HIP runtime may already be unloading: then the cache is left to the
+// process teardown.  The flag is raised by an atexit handler registered when the first cache is created, i.e. after the HIP
+// runtime registered its own, so it runs before them.
+std::atomic<bool> g_process_exiting(false);
+void note_process_exit() { g_process_exiting.store(true); }
+struct CtxHolder {
+    DeviceCtx c;
+    CtxHolder() { static const int once = atexit(note_process_exit); (void)once; }
+    ~CtxHolder() { if (!g_process_exiting.load()) c.release(); }
+};
 thread_local CtxHolder g_ctx;
 
 // Bump allocator over the cached arena.  In `staged` mode uploads are memcpy'd into the pinned mirror at the same
@@ -260,7 +271,8 @@ struct DevBuf {
 
 } // namespace
 
-static int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per host thread, like the cache and the error string
+static thread_local char g_kernel_name[64] = "dd_hmm_kernel";
 
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
@@ -271,7 +283,13 @@ extern "C" {
 
 int dd_abi_version(void) { return DD_ABI_VERSION; }
 const char *dd_last_error(void) { return g_err.c_str(); }
-const char *dd_kernel_name(void) { return "dd_hmm_kernel"; }
+const char *dd_kernel_name(void)
+{   // the template instance this host thread launched last, as rocprofv3 prints it (inside "void ddk::...(ddk::KernelArgs)")
+    const int K = g_last_launch[0], D = g_last_launch[1];
+    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s>", K, D % 100, D >= 100 ? "true" : "false");
+    else if (K > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_faster_kernel");
+    return g_kernel_name;
+}
 
 void dd_last_launch(int32_t out[8])
 {   // K, D build, waves per workgroup, LDS bytes per workgroup, grid, read split, LDS per wave, shared LDS
@@ -339,6 +357,36 @@ int dd_batch_sizes(const dd_batch *b, dd_sizes *out)
         out->cells += SH * SL;
     }
     return DD_SUCCESS;
+}
+
+int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[2])
+{
+    if (!b || !win_skip) return fail(DD_ERR_INVALID, "null argument");
+    if (b->n_windows < 0 || !b->win_hap_off || !b->win_read_off || !b->hap_seq_off || !b->read_seq_off)
+        return fail(DD_ERR_INVALID, "null offset array");
+    int n_skip = 0, mh = 0, mr = 0;
+    for (int w = 0; w < b->n_windows; w++) {
+        int wh = 0, wr = 0;
+        bool bad = false;
+        for (int h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
+            const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+            if (len < 1 || len > DD_MAX_HAP_LEN) bad = true;
+            if (len > wh) wh = len;
+        }
+        for (int q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
+            const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+            if (len < 1 || len > DD_MAX_READ_LEN) bad = true;
+            if (len > wr) wr = len;
+        }
+        win_skip[w] = bad ? 1 : 0;
+        if (bad) { n_skip++; continue; }
+        if (b->win_hap_off[w + 1] > b->win_hap_off[w] && b->win_read_off[w + 1] > b->win_read_off[w]) {   // windows with pairs
+            if (wh > mh) mh = wh;
+            if (wr > mr) mr = wr;
+        }
+    }
+    if (max_len_out) { max_len_out[0] = mh; max_len_out[1] = mr; }
+    return n_skip;
 }
 
 int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off)
@@ -485,24 +533,30 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
 static const int kHapClassBounds[DD_N_HAP_CLASSES] = {62, 126, 190, 254, 382, 510, DD_MAX_HAP_LEN};   // 64*K - 2
 static const int kReadClassBounds[2] = {160, DD_MAX_READ_LEN};
 
-int dd_build_length_classes(const dd_batch *b, int32_t *hap_class_list, dd_length_classes *out)
+int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out)
 {
     if (!b || !hap_class_list || !out) return fail(DD_ERR_INVALID, "null argument");
     dd_sizes sz;
     int rc = dd_batch_sizes(b, &sz);
     if (rc) return rc;
     memset(out, 0, sizeof(*out));
-    if (sz.max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766");
     std::vector<int> cls((size_t)sz.n_haps);
     int count[DD_N_HAP_CLASSES] = {0};
-    for (int64_t h = 0; h < sz.n_haps; h++) {
-        const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
-        int c = 0;
-        while (len > kHapClassBounds[c]) c++;
-        cls[(size_t)h] = c;
-        count[c]++;
-        if (len > out->hap_class_max[c]) out->hap_class_max[c] = len;
+    for (int w = 0; w < b->n_windows; w++) {
+        const bool skip = win_skip && win_skip[w];
+        for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
+            const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+            int c = 0;
+            if (!skip) {
+                if (len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766 in a window that is not flagged in win_skip");
+                while (len > kHapClassBounds[c]) c++;
+                if (len > out->hap_class_max[c]) out->hap_class_max[c] = len;
+            }
+            cls[(size_t)h] = c;              // haplotypes of skipped windows ride in class 0: the kernel only marks their pairs
+            count[c]++;
+        }
     }
+    if (count[0] > 0 && out->hap_class_max[0] == 0) out->hap_class_max[0] = 1;   // class 0 holds skipped haplotypes only: still launched
     for (int c = 0; c < DD_N_HAP_CLASSES; c++) out->hap_class_off[c + 1] = out->hap_class_off[c] + count[c];
     int fill[DD_N_HAP_CLASSES];
     for (int c = 0; c < DD_N_HAP_CLASSES; c++) fill[c] = out->hap_class_off[c];
@@ -510,12 +564,18 @@ int dd_build_length_classes(const dd_batch *b, int32_t *hap_class_list, dd_lengt
     int lo = 1;
     for (int k = 0; k < 2; k++) {
         int mx = 0;
-        for (int64_t q = 0; q < sz.n_reads; q++) {
-            const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
-            if (len >= lo && len <= kReadClassBounds[k] && len > mx) mx = len;
+        for (int w = 0; w < b->n_windows; w++) {
+            if (win_skip && win_skip[w]) continue;
+            for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
+                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+                if (len >= lo && len <= kReadClassBounds[k] && len > mx) mx = len;
+            }
         }
         if (mx) { out->read_class_lo[out->n_read_classes] = lo; out->read_class_max[out->n_read_classes] = mx; out->n_read_classes++; }
         lo = kReadClassBounds[k] + 1;
+    }
+    if (out->n_read_classes == 0 && sz.n_reads > 0) {   // every window skipped: one (dummy) read class so that the marking launch happens
+        out->read_class_lo[0] = 1; out->read_class_max[0] = 1; out->n_read_classes = 1;
     }
     return DD_SUCCESS;
 }
@@ -695,7 +755,7 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     A.read_seq_off = b->read_seq_off; A.read_seq = b->read_seq; A.read_qidx = b->read_qidx; A.read_mqidx = b->read_mqidx;
     A.read_start = b->read_start; A.read_flags = b->read_flags;
     A.hap_window = b->hap_window; A.win_pair_off = b->win_pair_off; A.win_hpos_off = b->win_hpos_off;
-    A.win_varcov_off = b->win_varcov_off; A.tables = b->tables; A.sym_lut = b->sym_lut;
+    A.win_varcov_off = b->win_varcov_off; A.tables = b->tables; A.sym_lut = b->sym_lut; A.win_skip = b->win_skip;
     if (p->mapUnmappedReads && model == MODEL_FBMAXERR) {   // the --faster model has no insert-size prior
         if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib || !b->lib_off || !b->lib_logprob || !b->lib_log95)
             return fail(DD_ERR_INVALID, "mapUnmappedReads needs the mate arrays and the library log tables");
@@ -984,8 +1044,13 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         return fail(DD_ERR_INVALID, "null input array");
     if (b->n_qual < 1 || b->n_qual > DD_MAX_QUAL_TABLE || b->n_mapq < 1 || b->n_mapq > DD_MAX_QUAL_TABLE)
         return fail(DD_ERR_INVALID, "quality tables must hold 1..256 entries");
-    for (int64_t h = 0; h < sz.n_haps; h++)
-        if (b->hap_seq_off[h + 1] - b->hap_seq_off[h] < 1) return fail(DD_ERR_INVALID, "empty haplotype");
+    // windows whose shape the kernels do not cover are skipped one by one (DD_PAIR_UNSUPPORTED), not the batch
+    std::vector<uint8_t> win_skip((size_t)b->n_windows);
+    int32_t ok_max[2] = {0, 0};
+    const int n_skip = dd_screen_windows(b, win_skip.data(), ok_max);
+    if (n_skip < 0) return n_skip;
+    sz.max_hap_len = ok_max[0] > 0 ? ok_max[0] : 1;      // planning maxima: the windows that are computed
+    sz.max_read_len = ok_max[1] > 0 ? ok_max[1] : 1;
     uint8_t sym_lut[256];
     if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
     std::vector<double> lib_logprob, lib_log95;
@@ -999,18 +1064,14 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         for (int64_t q = 0; q < sz.n_reads; q++)
             if (b->read_lib[q] >= b->n_libs) return fail(DD_ERR_INVALID, "read_lib out of range");
     }
-    for (int64_t q = 0; q < sz.n_reads; q++) {
-        if (b->read_seq_off[q + 1] - b->read_seq_off[q] < 1) return fail(DD_ERR_INVALID, "empty read");
+    for (int64_t q = 0; q < sz.n_reads; q++)
         if (b->read_mqidx[q] >= b->n_mapq) return fail(DD_ERR_INVALID, "read_mqidx out of range");
-    }
     for (int64_t i = 0; i < sz.read_bases; i++)
         if (b->read_qidx[i] >= b->n_qual) return fail(DD_ERR_INVALID, "read_qidx out of range");
     for (int i = 0; i < b->n_qual; i++)
         if (!(b->qual_table[i] >= 0.0 && b->qual_table[i] <= 1.0)) return fail(DD_ERR_INVALID, "base quality outside [0,1]");
     for (int i = 0; i < b->n_mapq; i++)
         if (!(b->mapq_table[i] >= 0.0 && b->mapq_table[i] < 1.0)) return fail(DD_ERR_INVALID, "mapping quality outside [0,1)");
-    if (sz.max_hap_len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766");
-    if (sz.max_read_len > DD_MAX_READ_LEN) return fail(DD_ERR_UNSUPPORTED, "read longer than 1024");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1039,26 +1100,34 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     if (const char *e = getenv("DD_READ_BOUND")) { const int v = atoi(e); if (v >= 1 && v < DD_MAX_READ_LEN) kReadBounds[0] = v; }   // A/B only
     struct HostClass { std::vector<int32_t> haps; int max_hap = 0; const int32_t *dev = nullptr; };
     std::vector<HostClass> hcls(DD_N_HAP_CLASSES);
-    for (int64_t h = 0; h < sz.n_haps; h++) {
-        const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
-        size_t c = 0;
-        while (len > kHapBounds[c]) c++;
-        hcls[c].haps.push_back((int32_t)h);
-        if (len > hcls[c].max_hap) hcls[c].max_hap = len;
-    }
+    for (int w = 0; w < W; w++)
+        for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
+            const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+            size_t c = 0;
+            if (!win_skip[(size_t)w]) {          // haplotypes of skipped windows ride in class 0 (their pairs are only marked)
+                while (len > kHapBounds[c]) c++;
+                if (len > hcls[c].max_hap) hcls[c].max_hap = len;
+            }
+            hcls[c].haps.push_back((int32_t)h);
+        }
+    if (!hcls[0].haps.empty() && hcls[0].max_hap == 0) hcls[0].max_hap = 1;
     struct ReadClass { int lo, hi, max_len; };
     std::vector<ReadClass> rcls;
     {
         int lo = 1;
         for (int bound : kReadBounds) {
             int mx = 0;
-            for (int64_t q = 0; q < sz.n_reads; q++) {
-                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
-                if (len >= lo && len <= bound && len > mx) mx = len;
+            for (int w = 0; w < W; w++) {
+                if (win_skip[(size_t)w]) continue;
+                for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
+                    const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+                    if (len >= lo && len <= bound && len > mx) mx = len;
+                }
             }
             if (mx) rcls.push_back({lo, bound, mx});
             lo = bound + 1;
         }
+        if (rcls.empty()) rcls.push_back({1, kReadBounds[0], 1});       // every window skipped: the marking launch still runs
         if (getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k") && !rcls.empty()) {
             ReadClass all = {1, DD_MAX_READ_LEN, rcls.back().max_len};      // A/B: haplotype classes only
             rcls.assign(1, all);
@@ -1089,7 +1158,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
     const size_t in_bytes = (size_t)(W + 1) * (4 + 4 + 8 + 8 + 8) + (size_t)W * 4 + (size_t)(sz.n_haps + 1) * 8 + (size_t)sz.hap_bases +
                             (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 20 +
-                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 48 * 256 +
+                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 48 * 256 + (size_t)W + 256 +
                             (lib_log95.empty() ? 0 : (size_t)sz.n_reads * 9 + (lib_logprob.size() + lib_log95.size()) * 8 + (size_t)(b->n_libs + 1) * 4);
     const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + 2 * (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
     const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
@@ -1114,6 +1183,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     if ((rc = dev.upload(&db.win_varcov_off, (const int64_t *)vc_off.data(), vc_off.size()))) return rc;
     if ((rc = dev.upload(&db.tables, (const double *)tables.data(), tables.size()))) return rc;
     if ((rc = dev.upload(&db.sym_lut, (const uint8_t *)sym_lut, (size_t)256))) return rc;
+    if (n_skip > 0 && (rc = dev.upload(&db.win_skip, (const uint8_t *)win_skip.data(), win_skip.size()))) return rc;
     if (!lib_log95.empty()) {
         if ((rc = dev.upload(&db.read_mate_pos, b->read_mate_pos, (size_t)sz.n_reads))) return rc;
         if ((rc = dev.upload(&db.read_mate_len, b->read_mate_len, (size_t)sz.n_reads))) return rc;
@@ -1175,6 +1245,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         DOWN(onHap, b->win_read_off[w0], b->win_read_off[w1] - b->win_read_off[w0]);
         return DD_SUCCESS;
     };
+    auto enqueue_and_collect = [&]() -> int {
     for (int c = 0; c < n_chunks; c++) {
         const int w0 = cw[c], w1 = cw[c + 1];
         const int g0 = b->win_hap_off[w0], g1 = b->win_hap_off[w1], q0 = b->win_read_off[w0], q1 = b->win_read_off[w1];
@@ -1216,8 +1287,19 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         HIP_TRY(hipStreamSynchronize(streams.s[0]));
         HIP_TRY(hipStreamSynchronize(streams.s[1]));
     }
-#undef DOWN
     return DD_SUCCESS;
+    };
+#undef DOWN
+    rc = enqueue_and_collect();
+    if (rc != DD_SUCCESS) {
+        // kernels / copies already enqueued keep writing into the caller's buffers and this thread's arena: drain both
+        // streams before the error is reported, so that neither is reused while still in flight
+        const std::string msg = g_err;
+        (void)hipStreamSynchronize(streams.s[0]);
+        (void)hipStreamSynchronize(streams.s[1]);
+        g_err = msg;
+    }
+    return rc;
 }
 
 } // extern "C"

@@ -21,6 +21,7 @@
 //   bt    u8[L][16]          back-pointers of diagonal d's two states in one byte (encoding at bt_left / bt_right)
 //   bc    double2[16]        the per-base exchange slots (later: coverage bitmap);  srt int[16]: sorted relative positions
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <type_traits>
 #include "hmm_kernel.h"
@@ -114,6 +115,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int g = item / P.n_split, split = item - g * P.n_split;
         const int w = P.hap_window[g], h0 = P.win_hap_off[w];
         const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1], R = r1 - r0;
+        if (P.win_skip && P.win_skip[w]) {
+            // window outside the kernel limits (dd_screen_windows): its pairs are only marked, nothing of it is read
+            const int64_t pb = P.win_pair_off[w] + (int64_t)(g - h0) * R;
+            for (int ri = split * (int)blockDim.x + tid; ri < R; ri += P.n_split * (int)blockDim.x) {
+                P.out.status[pb + ri] = DD_PAIR_UNSUPPORTED;
+                P.out.ll[pb + ri] = 0.0;
+                if (P.out.offHap) P.out.offHap[pb + ri] = 1;
+                if (P.out.offHapHMQ) P.out.offHapHMQ[pb + ri] = 1;
+            }
+            continue;
+        }
         const int hs_off = P.hap_seq_off[g], hlen = P.hap_seq_off[g + 1] - hs_off;
         const uint32_t hapStart = P.win_hap_start[w];
         const char *hap = P.hap_seq + hs_off;
@@ -564,8 +576,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_faster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // raised once per device to the CU's 160 KiB (see launch_one in hmm_kernel.hip: a per-launch value races between host threads)
+    static std::atomic<unsigned> raised(0u);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_faster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised.fetch_or(bit, std::memory_order_release);
+    }
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dd_faster_kernel, dim3(grid), dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }

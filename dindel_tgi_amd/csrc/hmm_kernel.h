@@ -48,6 +48,7 @@ struct KernelArgs {
     const int64_t *win_pair_off, *win_hpos_off, *win_varcov_off;
     const double *tables;
     const uint8_t *sym_lut;              /* byte -> symbol id (dd_build_symbol_lut); NULL = A,C,G,T,N only */
+    const uint8_t *win_skip;             /* per window: 1 = shape outside the kernel limits, pairs only get DD_PAIR_UNSUPPORTED; NULL = none */
     /* mapUnmappedReads: mate arrays + library log tables; read_mate_pos == NULL switches the insert-size prior off */
     const int32_t *read_mate_pos, *read_mate_len; const uint8_t *read_lib;
     const int32_t *lib_off; const double *lib_logprob, *lib_log95;

@@ -26,6 +26,7 @@
 // recurrence, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "hmm_kernel.h"
 
 namespace ddk {
@@ -132,6 +133,15 @@ __device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double
 // Back-pointer packing: per position CB bits of transition choice (0 = from the inserted state, y = jump
 // length; LO/RO use their own small codes) + 1 bit for the inserted state's choice.  D <= 7 -> 4 bits per
 // position, else 5.  One lane's K positions of one slice go into one 1/2/4/8-byte word in LDS.
+// a pair of a window that dd_screen_windows flagged: DD_PAIR_UNSUPPORTED, ll = 0, "off the haplotype"
+__device__ __forceinline__ void mark_unsupported(const dd_result &o, int64_t pair)
+{
+    o.status[pair] = DD_PAIR_UNSUPPORTED;
+    o.ll[pair] = 0.0;
+    if (o.offHap) o.offHap[pair] = 1;
+    if (o.offHapHMQ) o.offHapHMQ[pair] = 1;
+}
+
 template <int K, int D> struct BtPack {
     static constexpr int CB = (D <= 7) ? 3 : 4;
     static constexpr int PB = CB + 1;
@@ -222,6 +232,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     const int h0 = P.win_hap_off[w];
     const int r0 = P.win_read_off[w], r1 = P.win_read_off[w + 1];
     const int R = r1 - r0;
+    if (P.win_skip && P.win_skip[w]) {
+        // window outside the kernel limits (dd_screen_windows): its pairs are only marked, nothing of it is read
+        const int64_t pb = P.win_pair_off[w] + (int64_t)(g - h0) * R;
+        for (int ri = split * nthr + tid; ri < R; ri += P.n_split * nthr) mark_unsupported(P.out, pb + ri);
+        continue;
+    }
     const int hs_off = P.hap_seq_off[g];
     const int Hs = P.hap_seq_off[g + 1] - hs_off;
     const int numS = Hs + 2, RO = Hs + 1;
@@ -921,7 +937,8 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
     int on = 0;
     for (int h = 0; h < H; h++) {
         const int64_t p = base + (int64_t)h * R;
-        if (P.out.status[p] != DD_PAIR_HAPSIZE && !P.out.offHapHMQ[p]) on = 1;
+        const int st = P.out.status[p];
+        if (st != DD_PAIR_HAPSIZE && st != DD_PAIR_UNSUPPORTED && !P.out.offHapHMQ[p]) on = 1;
     }
     P.out.onHap[r] = (uint8_t)on;
 }
@@ -929,9 +946,21 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
 template <int K, int D, bool GBT>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // The cap on dynamic LDS is a property of the function, not of a launch: it is raised ONCE per template instance (and
+    // per device) to the CU's 160 KiB, so that host threads launching the same instance with different tile sizes cannot
+    // lower it under each other between the set and the launch.
+    static std::atomic<unsigned> raised(0u);             // bit d: done on device d
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised.fetch_or(bit, std::memory_order_release);
+    }
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
     hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT>), grid, dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }

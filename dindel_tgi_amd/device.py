@@ -68,15 +68,24 @@ class DeviceBatch:
         if pb.hap_var_flank is not None and len(pb.hap_var_flank):
             t["hap_var_flank"] = _to_dev(pb.hap_var_flank, self.device)
         # ragged batches: per-class launch plans (haplotype length x read length), as the host-pointer path does by itself
+        # windows outside the kernel limits are marked (DD_PAIR_UNSUPPORTED), not computed: flags + the maxima of the rest
+        skip = np.zeros(max(pb.n_windows, 1), np.uint8)
+        ok_max = (C.c_int32 * 2)()
+        self.n_skipped = lib.dd_screen_windows(C.byref(hb), skip.ctypes.data_as(capi.c_u8p), C.byref(ok_max))
+        if self.n_skipped < 0:
+            raise RuntimeError("dd_screen_windows: " + capi.last_error())
+        if self.n_skipped:
+            t["win_skip"] = _to_dev(skip, self.device)
         self.classes = capi.dd_length_classes()
         hcl = np.zeros(max(pb.n_haps, 1), np.int32)
-        if lib.dd_build_length_classes(C.byref(hb), hcl.ctypes.data_as(capi.c_i32p), C.byref(self.classes)) != 0:
+        if lib.dd_build_length_classes(C.byref(hb), skip.ctypes.data_as(capi.c_u8p) if self.n_skipped else None,
+                                       hcl.ctypes.data_as(capi.c_i32p), C.byref(self.classes)) != 0:
             raise RuntimeError("dd_build_length_classes: " + capi.last_error())
         t["hap_class_list"] = _to_dev(hcl, self.device)
         self.t = t
         db = capi.dd_device_batch()
         db.n_windows, db.n_haps, db.n_reads = pb.n_windows, pb.n_haps, pb.n_reads
-        db.max_hap_len, db.max_read_len = pb.max_hap_len, pb.max_read_len
+        db.max_hap_len, db.max_read_len = max(int(ok_max[0]), 1), max(int(ok_max[1]), 1)
         for k, v in t.items():
             setattr(db, k, v.data_ptr())
         db.n_qual, db.n_mapq = hb.n_qual, hb.n_mapq

@@ -353,6 +353,10 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
             for (size_t r = 0; r < Rn; r++) {
                 const int64_t p = pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
                 if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47, Faster.cpp:47
+                if (status[p] == DD_PAIR_UNSUPPORTED) {      // this window only; the caller skips it like a window that threw (DInDel.cpp:1369-1374)
+                    J.error = "window outside the GPU kernel limits (haplotype > 766 bp, read > 1024 bp or an empty sequence)";
+                    break;
+                }
                 if (faster && status[p] != DD_PAIR_OK) { J.error = "HapHash string too short"; break; }   // Haplotype.hpp:341
                 MLAlignment &ml = (*J.liks)[h][r];
                 const Read &Rd = (*J.reads)[r];

@@ -8,6 +8,8 @@
 //   * haplotype shorter than maxLengthDel  -> throws std::string("hapSize error.")   (ObservationModelFB.cpp:47)
 //   * NaN / Inf log-likelihood             -> throws std::string("Nan detected")     (DInDel.cpp:1732-1735)
 //   * log-likelihood > 0.1                 -> "Likelihood>0" on stderr, exit(1)      (DInDel.cpp:1722-1731)
+//   * window shape outside the kernel limits (haplotype > 766 bp, read > 1024 bp, empty sequence; no reference
+//     counterpart) -> throws std::string("window outside the GPU kernel limits ...") for THAT window only
 //                                             (setThrowOnPositiveLikelihood(true) turns the exit into a throw)
 // All arithmetic runs on the GPU through the C ABI (include/dindel_hmm.h); this class only packs the
 // windows, calls dd_compute_likelihoods and rebuilds the MLAlignment records (variant strings from hpos).

@@ -65,8 +65,12 @@ extern "C" {
 #define DD_PAIR_HAPSIZE       1
 #define DD_PAIR_NAN           2
 #define DD_PAIR_LLPOS         3
+#define DD_PAIR_UNSUPPORTED   4   /* the pair's WINDOW has a shape outside the kernel limits below (or an empty read / haplotype): none of
+                                     its pairs is computed (ll = 0, offHap = offHapHMQ = 1, onHap = 0, the other outputs unwritten); every
+                                     other window of the batch is processed normally.  The reference has no such limit: the C++ adapter
+                                     reports the window like one whose likelihood step threw (skipped row, DInDel.cpp:1369-1374). */
 
-/* kernel limits (checked on the host before launch) */
+/* kernel limits (screened per window on the host before launch: dd_screen_windows) */
 #define DD_MAX_HAP_LEN      766   /* numS = Hs+2 <= 64 lanes x 12 positions                         */
 #define DD_MAX_READ_LEN    1024
 #define DD_MAX_LENGTH_DEL    11   /* D = maxLengthDel+1 <= 12: choice fits 4 bits, 5*D match bits fit 64 */
@@ -185,6 +189,13 @@ typedef struct dd_sizes {
 
 int dd_batch_sizes(const dd_batch *b, dd_sizes *out);
 
+/* Per-window shape screen: win_skip[w] = 1 iff window w holds a haplotype longer than DD_MAX_HAP_LEN, a read longer than
+ * DD_MAX_READ_LEN, or an empty haplotype / read; its pairs get DD_PAIR_UNSUPPORTED instead of failing the whole batch.
+ * max_len_out[2] (may be NULL) = longest haplotype / read among the windows that pass.  Returns the number of skipped
+ * windows (>= 0) or a DD_ERR_* code.  dd_compute_likelihoods does this by itself; callers of dd_launch_device upload
+ * win_skip (dd_device_batch.win_skip) and plan with the returned maxima. */
+int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[2]);
+
 /* Offsets a consumer needs to index the ragged outputs; arrays sized [n_windows+1]. */
 int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off);
 
@@ -230,8 +241,10 @@ typedef struct dd_length_classes {
     int32_t n_read_classes;                       /* 0..2                                                                  */
     int32_t read_class_lo[2], read_class_max[2];  /* shortest admissible / longest present read length of each read class  */
 } dd_length_classes;
-/* hap_class_list[n_haps]: haplotype indices sorted by class, ascending inside a class (host memory; copy it to the device) */
-int dd_build_length_classes(const dd_batch *b, int32_t *hap_class_list, dd_length_classes *out);
+/* hap_class_list[n_haps]: haplotype indices sorted by class, ascending inside a class (host memory; copy it to the device).
+ * win_skip (may be NULL = none): dd_screen_windows' flags; haplotypes of skipped windows ride in class 0 without counting
+ * towards its maximum (the kernel only marks their pairs), and their reads do not count towards the read classes. */
+int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out);
 
 typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_batch */
     int32_t n_windows, n_haps, n_reads;
@@ -252,6 +265,8 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
     /* optional, both or neither: per-class launches for ragged batches (main model only) */
     const int32_t *hap_class_list;          /* DEVICE copy of dd_build_length_classes' list */
     const dd_length_classes *classes;       /* HOST pointer */
+    const uint8_t *win_skip;                /* optional: DEVICE copy of dd_screen_windows' flags [n_windows]; NULL = every window is
+                                               within the limits (max_hap_len / max_read_len then cover the whole batch) */
 } dd_device_batch;
 
 /* bytes of device scratch dd_launch_device needs for this shape (0 if none) */

@@ -204,7 +204,7 @@ def test_length_classes_and_library_tables_on_the_host(lib):
     b = pb.ctypes_batch()
     cls = capi.dd_length_classes()
     lst = np.zeros(pb.n_haps, np.int32)
-    assert lib.dd_build_length_classes(C.byref(b), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     hl = np.diff(pb.a["hap_seq_off"])
     c = np.searchsorted([62, 126, 190, 254, 382, 510, 766], hl, side="left")
     assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=7)).tolist()
@@ -219,3 +219,33 @@ def test_length_classes_and_library_tables_on_the_host(lib):
     assert lp.tolist() == [math.log(x) for x in (0.1, 0.2, 0.3, 0.4, 1.0)] and l95.tolist() == [math.log(0.3), 0.0]
     bad = pack(wins, libraries=[(np.array([0.5, 0.0]), 0.5)])
     assert lib.dd_build_library_tables(C.byref(bad.ctypes_batch()), lp.ctypes.data_as(capi.c_f64p), l95.ctypes.data_as(capi.c_f64p)) == capi.DD_ERR_INVALID
+
+
+def test_screen_windows_flags_only_the_offending_windows(lib):
+    """dd_screen_windows: a haplotype > 766 bp, a read > 1024 bp or an empty read / haplotype flags ITS window; the maxima
+    are those of the windows that pass; dd_build_length_classes keeps skipped haplotypes out of the class maxima."""
+    rng = np.random.default_rng(9)
+    def seq(n):
+        return "".join(rng.choice(list("ACGT"), n))
+    good = Window(1000, [seq(100), seq(130)], [ReadRec(seq(80), [0.99] * 80, 0.99, 1000)])
+    long_hap = Window(1000, [seq(767), seq(50)], [ReadRec(seq(40), [0.99] * 40, 0.99, 1000)])
+    long_read = Window(1000, [seq(60)], [ReadRec(seq(1025), [0.99] * 1025, 0.99, 1000), ReadRec(seq(30), [0.99] * 30, 0.99, 1000)])
+    empty_read = Window(1000, [seq(60)], [ReadRec("", [], 0.99, 1000)])
+    limit = Window(1000, [seq(766)], [ReadRec(seq(1024), [0.99] * 1024, 0.99, 1000)])
+    pb = pack([good, long_hap, long_read, good, empty_read])
+    b = pb.ctypes_batch()
+    skip = np.full(pb.n_windows, 7, np.uint8)
+    mx = (C.c_int32 * 2)()
+    assert lib.dd_screen_windows(C.byref(b), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 3
+    assert skip.tolist() == [0, 1, 1, 0, 1] and list(mx) == [130, 80]
+    cls = capi.dd_length_classes()
+    lst = np.zeros(pb.n_haps, np.int32)
+    assert lib.dd_build_length_classes(C.byref(b), skip.ctypes.data_as(capi.c_u8p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    assert sorted(lst.tolist()) == list(range(pb.n_haps))
+    assert list(cls.hap_class_max) == [1, 100, 130, 0, 0, 0, 0]          # class 0 holds the skipped haplotypes only
+    assert list(cls.hap_class_off) == [0, 4, 6, 8, 8, 8, 8, 8]
+    assert cls.n_read_classes == 1 and cls.read_class_max[0] == 80
+    assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == capi.DD_ERR_UNSUPPORTED
+    pb2 = pack([limit, good])
+    assert lib.dd_screen_windows(C.byref(pb2.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 0
+    assert list(mx) == [766, 1024]

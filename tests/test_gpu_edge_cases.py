@@ -349,3 +349,56 @@ def test_device_pointer_path_uses_length_classes(lib):
     dev.launch()
     torch.cuda.synchronize()
     assert_same(dev.results(), _oracle.batch(p, pb, nthreads=8), pb)
+
+
+@pytest.mark.parametrize("faster", [False, True])
+def test_unsupported_window_fails_alone(lib, faster):
+    """A window outside the kernel limits (haplotype > 766 bp, read > 1024 bp, empty read) gets DD_PAIR_UNSUPPORTED on its
+    own pairs; every other window of the batch equals the oracle — host-pointer path, device-pointer path (per-class
+    launches) and both models.  (Round 1 failed the whole batch: one 767-bp haplotype in a fuzz round.)"""
+    import torch
+    from dindel_tgi_amd.batch import pair_slices
+    from dindel_tgi_amd.device import DeviceBatch
+    p = capi.params_cli_defaults()
+    hapA, hapB, hapL = rnd(110), rnd(300), rnd(767)
+    good1 = Window(1000, [hapA, hapA[:50] + hapA[52:]], reads_from(hapA, 9, 70))
+    good2 = Window(1000, [hapB], reads_from(hapB, 5, 200, junk=0.0) + reads_from(hapB, 3, 60))
+    bad_hap = Window(1000, [hapA, hapL], reads_from(hapA, 4, 50))
+    bad_read = Window(1000, [hapA], reads_from(hapA, 2, 60) + [ReadRec(rnd(1025), [0.99] * 1025, 0.99, 1000)])
+    bad_empty = Window(1000, [hapA], [ReadRec("", [], 0.99, 1000)] + reads_from(hapA, 2, 60))
+    ws = [good1, bad_hap, good2, bad_read, bad_empty, good1]
+    bad = [1, 3, 4]
+    pb = pack(ws)
+    want = _oracle.batch(p, pack([w if i not in bad else Window(1000, [hapA], []) for i, w in enumerate(ws)]), nthreads=4, faster=faster)
+    pw = pack([w if i not in bad else Window(1000, [hapA], []) for i, w in enumerate(ws)])
+
+    def check_result(got):
+        for w in range(len(ws)):
+            p0, H, R, h0, SL, _ = pair_slices(pb, w)
+            r0 = int(pb.a["win_read_off"][w])
+            if w in bad:
+                assert (got["status"][p0:p0 + H * R] == capi.DD_PAIR_UNSUPPORTED).all()
+                assert (got["ll"][p0:p0 + H * R] == 0).all() and got["offHapHMQ"][p0:p0 + H * R].all()
+                assert not got["onHap"][r0:r0 + R].any()
+                continue
+            q0, _, _, g0, _, _ = pair_slices(pw, w)
+            s0 = int(pw.a["win_read_off"][w])
+            for k in ("ll", "llOn", "llOff", "mLogBQ", "status", "offHap", "offHapHMQ", "numIndels", "firstBase", "lastBase"):
+                assert np.array_equal(got[k][p0:p0 + H * R], want[k][q0:q0 + H * R]), (w, k)
+            assert np.array_equal(got["hpos"][h0:h0 + H * SL], want["hpos"][g0:g0 + H * SL]), w
+            assert np.array_equal(got["onHap"][r0:r0 + R], want["onHap"][s0:s0 + R]), w
+
+    arrs, res = alloc_result(pb, fill=None)
+    fn = lib.dd_compute_likelihoods_faster if faster else lib.dd_compute_likelihoods
+    assert fn(C.byref(p), C.byref(pb.ctypes_batch()), C.byref(res), 0) == 0, capi.last_error()
+    check_result(arrs)
+    dev = DeviceBatch(pb, p, "cuda:0")
+    assert dev.n_skipped == 3
+    (dev.launch_faster if faster else dev.launch)()
+    torch.cuda.synchronize()
+    check_result(dev.results())
+    # every window skipped: the call still succeeds and marks them all
+    pb2 = pack([bad_hap, bad_read])
+    arrs, res = alloc_result(pb2, fill=None)
+    assert fn(C.byref(p), C.byref(pb2.ctypes_batch()), C.byref(res), 0) == 0, capi.last_error()
+    assert (arrs["status"][:pb2.n_pairs] == capi.DD_PAIR_UNSUPPORTED).all() and not arrs["onHap"][:pb2.n_reads].any()
