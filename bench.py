@@ -6,9 +6,17 @@ log-likelihoods, flags, hpos, QC counters) over one batch of synthetic windows t
 in HBM.  Workload at N=1 is BASELINE.json configs[1]: 10,000 windows x 8 haplotypes x 200 reads
 (100 bp, Q30), CLI-default model parameters.  With N>1 every rank owns its own contiguous block of
 10,000 windows (weak scaling), and each step ends with the RCCL gather of the per-pair log-likelihoods
-and off-haplotype flags to rank 0 that north_star names.
+and off-haplotype flags to rank 0 that north_star names.  `--total-windows T` switches to strong scaling
+(BASELINE.json configs[3]: one job of T windows, rank r takes the r-th contiguous block, in sub-batches
+that fit the int32 read-base offsets of a batch).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000]
+`value` is the kernel path on HBM-resident inputs.  At N=1 the line also carries what SURVEY §8(d) defines
+windows/s on: `windows_per_s_incl_copies` (dd_compute_likelihoods with host pointers: H2D + kernels + D2H)
+and `windows_per_s_end_to_end` (dindel::LikelihoodEngine::computeLikelihoodsBatch on the reference's own
+C++ objects: pack + H2D + kernels + D2H + per-window status scan, records delivered as lazy views), with
+the split and the eager-record rate under `end_to_end`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000] [--total-windows T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -108,9 +116,14 @@ def main():
     ap.add_argument("--hap-len", type=int, default=120)
     ap.add_argument("--max-length-del", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-api", action="store_true",
-                    help="also time dd_compute_likelihoods (host pointers in/out: H2D + kernels + D2H) once and report it "
-                         "as host_api; never used for `value`")
+    ap.add_argument("--host-api", action="store_true", help="(kept for old command lines: the host-API legs now run by default at N=1)")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="skip the N=1 legs that time the host API (copies included) and the C++ adapter end to end")
+    ap.add_argument("--total-windows", type=int, default=0,
+                    help="strong scaling: ONE job of this many windows split over the ranks in contiguous blocks "
+                         "(BASELINE.json configs[3] = 1000000); default 0 = weak scaling with --windows per GPU")
+    ap.add_argument("--max-batch-windows", type=int, default=50000,
+                    help="strong scaling: largest sub-batch a rank keeps resident (a batch holds < 2^31 read bases)")
     ap.add_argument("--faster", action="store_true",
                     help="time the secondary --faster model (ObservationModelS, SURVEY row A13) instead of the headline path; "
                          "the JSON line then names that model in `metric` and is not the BASELINE metric")
@@ -139,10 +152,32 @@ def main():
     params = capi.params_cli_defaults()
     params.maxLengthDel = args.max_length_del
     # rank r owns windows [r*W, (r+1)*W) of the job; its block is generated from seed+r
-    pb = synth.generate(args.windows, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len,
-                        seed=0x9E3779B9 + rank)
-    dev = DeviceBatch(pb, params, device)
+    strong = args.total_windows > 0
+    if strong:
+        from dindel_tgi_amd.shard import window_block
+        w0, w1 = window_block(args.total_windows, rank, world)
+        n_mine = w1 - w0
+        n_sub = max(1, -(-n_mine // args.max_batch_windows))
+        bs = n_mine // n_sub                       # n_sub sub-batches of bs windows (+ one of `rem` windows)
+        rem = n_mine - bs * n_sub
+        gen = min(bs, 2500)                        # windows really generated; the rest are replicas (synthetic data either way)
+        base = synth.generate(gen, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len, seed=0x9E3779B9 + rank)
+        reps = -(-bs // gen)
+        pb = synth.tile(base, reps).slice_windows(0, bs) if reps * gen != bs else synth.tile(base, reps)
+        plan = [(DeviceBatch(pb, params, device), n_sub)]
+        if rem:
+            plan.append((DeviceBatch(pb.slice_windows(0, rem), params, device), 1))
+        dev = plan[0][0]
+        windows_this_rank = n_mine
+    else:
+        pb = synth.generate(args.windows, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len,
+                            seed=0x9E3779B9 + rank)
+        dev = DeviceBatch(pb, params, device)
+        plan = [(dev, 1)]
+        windows_this_rank = args.windows
     n_pairs, cells = pb.n_pairs, pb.cells
+    step_pairs = sum(d.pb.n_pairs * k for d, k in plan)
+    step_cells = sum(d.pb.cells * k for d, k in plan)
 
     GATHER = ("ll", "offHap", "offHapHMQ")          # per-pair records the downstream reduction consumes
     gather_bufs = None
@@ -151,17 +186,30 @@ def main():
         gather_bufs = {k: [torch.empty(dev.out[k].shape, dtype=dev.out[k].dtype, device=gdev) for _ in range(world)]
                        for k in GATHER}
 
-    def gather():
+    def gather(d=None):
+        d = d or dev
         for k in GATHER:
-            src = dev.out[k].cpu() if args.rehearse else dev.out[k]
-            dist.gather(src, gather_bufs[k] if rank == 0 else None, dst=0)
+            src = d.out[k].cpu() if args.rehearse else d.out[k]
+            if d is dev:
+                dist.gather(src, gather_bufs[k] if rank == 0 else None, dst=0)
+            else:                                   # the remainder sub-batch: same collective on the front of the buffers
+                n = src.numel()
+                dist.gather(src, [b[:n] for b in gather_bufs[k]] if rank == 0 else None, dst=0)
 
     launch = dev.launch_faster if args.faster else dev.launch
 
-    def step():
-        launch()
-        if world > 1:
-            gather()
+    def step(events=None):
+        for d, k in plan:
+            for _ in range(k):
+                if events is not None and d is dev:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                (d.launch_faster if args.faster else d.launch)()
+                if events is not None and d is dev:
+                    e1.record()
+                    events.append((e0, e1))
+                if world > 1:
+                    gather(d)
 
     for _ in range(args.warmup):
         step()
@@ -169,14 +217,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        launch()
-        ev[i][1].record()
-        if world > 1:
-            gather()
+        step(ev)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -186,34 +230,41 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")   # one launch of the main (sub-)batch
 
     # sanity: every pair finished with status OK and a finite negative log-likelihood
     res_status = dev.out["status"][:n_pairs]
     assert int((res_status != 0).sum().item()) == 0, "non-OK pair status in the bench batch"
     assert bool(torch.isfinite(dev.out["ll"][:n_pairs]).all().item())
 
-    if world > 1 and rank == 0:
+    if world > 1 and rank == 0 and len(plan) == 1:
         # the gathered block of rank 0 is its own result (sanity of the collective's layout)
         assert torch.equal(gather_bufs["ll"][0][:n_pairs].cpu(), dev.out["ll"][:n_pairs].cpu())
     if rank == 0:
-        total_cells = cells * world * args.steps
-        total_windows = args.windows * world * args.steps
+        if strong:      # every rank's block has the same per-window shape: the job's cells = this rank's x (job windows / its windows)
+            total_cells = int(step_cells * (args.total_windows / max(windows_this_rank, 1))) * args.steps
+            total_windows = args.total_windows * args.steps
+        else:
+            total_cells = cells * world * args.steps
+            total_windows = args.windows * world * args.steps
         value = total_cells / elapsed
         bpp = algorithmic_bytes_per_pair(args.read_len, args.hap_len, args.reads)
         achieved = bpp * n_pairs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "read-haplotype HMM cells/s", "value": value, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d windows/GPU x %d haplotypes x %d reads, %d bp reads (Q30), %d bp haplotypes, "
-                                   "maxLengthDel=%d (BASELINE.json configs[1])"
-                                   % (args.windows, args.haps, args.reads, args.read_len, args.hap_len, args.max_length_del),
-                       "windows_per_gpu": args.windows, "pairs_per_gpu": n_pairs, "cells_per_gpu": cells,
+            "config": {"workload": ("one job of %d windows over %d GPU(s) (BASELINE.json configs[3] shape), " % (args.total_windows, world) if strong
+                                    else "%d windows/GPU " % args.windows) +
+                                   "x %d haplotypes x %d reads, %d bp reads (Q30), %d bp haplotypes, maxLengthDel=%d%s"
+                                   % (args.haps, args.reads, args.read_len, args.hap_len, args.max_length_del,
+                                      "" if strong else " (BASELINE.json configs[1])"),
+                       "windows_per_gpu": windows_this_rank, "pairs_per_gpu": step_pairs, "cells_per_gpu": step_cells,
+                       "sub_batches_per_gpu": [[d.pb.n_windows, k] for d, k in plan],
                        "sharding": "contiguous window blocks per rank; gather of ll+flags to rank 0" if world > 1 else "single GPU"},
             "windows_per_s": total_windows / elapsed,
-            "pairs_per_s": n_pairs * world * args.steps / elapsed,
+            "pairs_per_s": total_cells / elapsed / (cells / n_pairs),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": (measured_traffic(n_pairs) or {}).get("bytes"),
@@ -226,7 +277,7 @@ def main():
             "valu_fp64": {"achieved_cells_per_s": cells / (kern_ms * 1e-3), "ceiling_cells_per_s": VALU_CELLS_PER_S,
                           "frac": cells / (kern_ms * 1e-3) / VALU_CELLS_PER_S},
         }
-        if args.host_api:
+        if world == 1 and not strong and not args.kernel_only:
             import ctypes as C
             from dindel_tgi_amd.batch import alloc_result
             lib = capi.load()
@@ -238,7 +289,27 @@ def main():
                 dt = time.perf_counter() - t0
                 assert rc == 0, capi.last_error()
             out["host_api"] = {"seconds": dt, "cells_per_s": cells / dt, "windows_per_s": args.windows / dt,
-                               "note": "dd_compute_likelihoods with host pointers: H2D of the batch, kernels, D2H of every output"}
+                               "note": "dd_compute_likelihoods with (pageable) host pointers: H2D of the batch, kernels, D2H of every output"}
+            out["windows_per_s_incl_copies"] = args.windows / dt
+            # the C++ drop-in: LikelihoodEngine::computeLikelihoodsBatch on vector<Haplotype> / vector<Read> objects of the same shape
+            from dindel_tgi_amd import hostlib
+            kw = dict(H=args.haps, R=args.reads, L=args.read_len, HL=args.hap_len, faster=args.faster, device=local_rank)
+            lazy = hostlib.bench_batch(args.windows, reps=2, **kw)
+            lean = hostlib.bench_batch(args.windows, reps=2, keep_alignments=False, **kw)
+            eager = hostlib.bench_batch(min(args.windows, 2000), reps=1, eager=True, **kw)
+            assert lazy["errors"] == lean["errors"] == eager["errors"] == 0
+            out["windows_per_s_end_to_end"] = args.windows / lazy["seconds"]
+            out["end_to_end"] = {
+                "what": "dindel::LikelihoodEngine::computeLikelihoodsBatch (C++ mirror of DetInDel::computeLikelihoods, DInDel.cpp:1707-1739) "
+                        "on %d windows of the same shape held as the reference's objects: pack + H2D + kernels + D2H + per-window "
+                        "status scan; records delivered as lazy views (every scalar in place, MLAlignment maps built on demand)" % args.windows,
+                "lazy_records": {"windows_per_s": args.windows / lazy["seconds"], **{k: lazy[k] for k in ("seconds", "pack", "device", "finish")}},
+                "lazy_records_no_alignments": {"windows_per_s": args.windows / lean["seconds"], **{k: lean[k] for k in ("seconds", "pack", "device", "finish")},
+                                               "note": "hpos (45 % of the result bytes) not copied back; a window is recomputed if a consumer asks for an alignment"},
+                "eager_records": {"windows_per_s": eager["windows"] / eager["seconds"], "windows": eager["windows"],
+                                  **{k: eager[k] for k in ("seconds", "pack", "device", "finish")},
+                                  "note": "every MLAlignment rebuilt (maps, strings, vectors) as the literal drop-in does"},
+                "frac_of_kernel_only": (args.windows / lazy["seconds"]) / (total_windows / elapsed)}
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would idle in the collective teardown)
             out["cpu_baseline"] = cpu_baseline(pb, params, faster=args.faster)
         if args.faster:

@@ -301,6 +301,18 @@ void dd_release_cache(void)
     g_ctx.c.release();
 }
 
+void *dd_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void dd_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int dd_device_count(void)
 {
     int n = 0;

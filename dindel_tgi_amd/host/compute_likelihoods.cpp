@@ -9,6 +9,8 @@
 #include <cstring>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include "../../include/dindel_hmm.h"
 
 namespace dindel {
@@ -184,6 +186,253 @@ void LikelihoodEngine::rebuildAlignmentFaster(const Haplotype &hap, const Read &
         ml.hapSNPCovered[it->first] = it->second.isCovered(p.padCover, ml.firstBase, ml.lastBase);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Flat buffers of a batch.  Result arrays are not value-initialised (4 GB of zero-fill per 10,000 windows would cost more
+// than the kernels) and live in page-locked memory when the device gives it (dd_host_alloc): the D2H copies then run at
+// link speed and overlap the kernels.
+template <class T> struct RawBuf {
+    T *p; size_t cap; bool pinned;
+    RawBuf() : p(NULL), cap(0), pinned(false) {}
+    ~RawBuf() { release(); }
+    void release() { if (p) { if (pinned) dd_host_free(p); else free(p); } p = NULL; cap = 0; }
+    T *reserve(size_t n)
+    {
+        if (n <= cap) return p;
+        release();
+        const size_t want = n + n / 8 + 64;
+        p = static_cast<T *>(dd_host_alloc(want * sizeof(T)));
+        pinned = p != NULL;
+        if (!p) p = static_cast<T *>(malloc(want * sizeof(T)));
+        if (!p) throw std::string("out of memory");
+        cap = want;
+        return p;
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+private:
+    RawBuf(const RawBuf &); RawBuf &operator=(const RawBuf &);
+};
+
+struct BatchBlock {
+    int W;
+    bool faster, has_hpos;
+    ObservationModelParameters params;
+    std::vector<int32_t> win_hap_off, win_read_off, hap_var_off, read_seq_off;
+    std::vector<int64_t> pair_off, hpos_off, vc_off;
+    RawBuf<double> ll, llOn, llOff, mLogBQ;
+    RawBuf<uint8_t> offHap, offHapHMQ, onHap, vcov, fcov;
+    RawBuf<int16_t> numIndels, numMismatch, nBQT, nmmBQT, nMMLeft, nMMRight, firstBase, lastBase, hpos;
+    RawBuf<int32_t> status;
+    BatchBlock() : W(0), faster(false), has_hpos(false) {}
+};
+
+struct PackScratch {
+    std::vector<int32_t> hap_seq_off, hap_var, hap_var_flank;
+    std::vector<uint32_t> win_hap_start, read_start;
+    std::vector<char> hap_seq, read_seq;
+    std::vector<uint8_t> read_qidx, read_mqidx, read_flags, read_lib;
+    std::vector<int32_t> read_mate_pos, read_mate_len;
+};
+
+namespace {
+
+// value -> small index, shared by the packing threads: a lock-free read of the per-thread cache, the shared table under a mutex
+// on a miss (at most 256 distinct values per batch: BAM qualities are integer Phred)
+class ValueTable {
+public:
+    std::vector<double> tab;
+    int intern(double v)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (size_t i = 0; i < tab.size(); i++)
+            if (memcmp(&tab[i], &v, sizeof(double)) == 0) return int(i);
+        if (tab.size() >= 256) return -1;
+        tab.push_back(v);
+        return int(tab.size()) - 1;
+    }
+private:
+    std::mutex m_;
+};
+
+struct ValueCache {                      // per thread: open addressing on the bit pattern
+    uint64_t key[512]; int16_t val[512];
+    ValueCache() { for (int i = 0; i < 512; i++) val[i] = -1; }
+    int get(double v, ValueTable &T)
+    {
+        uint64_t k;
+        memcpy(&k, &v, 8);
+        unsigned h = unsigned((k * 0x9E3779B97F4A7C15ull) >> 55);
+        for (;;) {
+            if (val[h] < 0) {
+                const int idx = T.intern(v);
+                if (idx < 0) return -1;
+                key[h] = k; val[h] = int16_t(idx);
+                return idx;
+            }
+            if (key[h] == k) return val[h];
+            h = (h + 1) & 511;
+        }
+    }
+};
+
+unsigned pick_threads(int hostThreads, int64_t units)
+{
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr > 16) nthr = 16;
+    if (nthr < 1) nthr = 1;
+    if (hostThreads > 0) nthr = unsigned(hostThreads);
+    if (int64_t(nthr) > units) nthr = unsigned(units > 0 ? units : 1);
+    return nthr;
+}
+
+template <class F> void parallel_windows(int W, unsigned nthr, int grain, F f)
+{
+    if (nthr <= 1 || W <= grain) { for (int w = 0; w < W; w++) f(w); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; t++)
+        pool.push_back(std::thread([&]() {
+            for (int w0 = next.fetch_add(grain); w0 < W; w0 = next.fetch_add(grain))
+                for (int w = w0; w < W && w < w0 + grain; w++) f(w);
+        }));
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+}
+
+// one record from the block (what the reference's loop body leaves in liks[h][r], DInDel.cpp:1717-1719)
+void fill_record(const BatchBlock &B, int w, size_t h, size_t r, const Haplotype &Hh, const Read &Rd, MLAlignment &ml)
+{
+    const size_t Rn = size_t(B.win_read_off[w + 1] - B.win_read_off[w]);
+    const int r0 = B.win_read_off[w];
+    const int g = B.win_hap_off[w] + int(h);
+    const int nv = B.hap_var_off[g + 1] - B.hap_var_off[g];
+    const int64_t p = B.pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
+    const int64_t SL = int64_t(B.read_seq_off[B.win_read_off[w + 1]]) - B.read_seq_off[r0];
+    const int L = int(Rd.size()), Hs = int(Hh.size());
+    const int16_t *hp = B.hpos.p + B.hpos_off[w] + int64_t(h) * SL + (B.read_seq_off[r0 + r] - B.read_seq_off[r0]);
+    const int64_t vb = B.vc_off[w] + int64_t(B.hap_var_off[g] - B.hap_var_off[B.win_hap_off[w]]) * int64_t(Rn) + int64_t(r) * nv;
+    // Per pair the device already delivers every counter of the record; the variant maps and the `align` string need the
+    // per-base walk (rebuildAlignment) only when the read shows an indel or differs from the haplotype segment it sits on.
+    bool plain = false;                       // gap-free, mismatch-free placement: nothing to list
+    if (!B.faster && B.numIndels[p] == 0) {
+        if (B.firstBase[p] < 0) plain = true;   // no base on the haplotype
+        else {
+            int b0 = 0;
+            while (b0 < L && hp[b0] < 0) b0++;
+            const int n = B.lastBase[p] - B.firstBase[p] + 1;
+            plain = b0 + n <= L && hp[b0] == B.firstBase[p] &&
+                    memcmp(Rd.seq.seq.data() + b0, Hh.seq.data() + B.firstBase[p], size_t(n)) == 0;
+        }
+    }
+    if (plain) {
+        ml.align = std::string(size_t(Hs), 'R');
+        ml.indels.clear(); ml.snps.clear(); ml.hapIndelCovered.clear(); ml.hapSNPCovered.clear();
+        ml.hpos.assign(hp, hp + L);              // no inserted base in a plain placement: the codes are the reference's
+        ml.firstBase = B.firstBase[p]; ml.lastBase = B.lastBase[p];
+        ml.numIndels = 0; ml.numMismatch = B.numMismatch[p]; ml.nBQT = B.nBQT[p]; ml.nmmBQT = B.nmmBQT[p];
+        ml.nMMLeft = B.nMMLeft[p]; ml.nMMRight = B.nMMRight[p];
+        int i = 0;
+        for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
+            ml.hapIndelCovered[it->first] = B.vcov[vb + i] != 0;
+        for (std::map<int, AlignedVariant>::const_iterator it = Hh.snps.begin(); it != Hh.snps.end(); ++it, ++i)
+            ml.hapSNPCovered[it->first] = B.vcov[vb + i] != 0;
+    } else if (B.faster) LikelihoodEngine::rebuildAlignmentFaster(Hh, Rd, hp, B.params, ml);
+    else LikelihoodEngine::rebuildAlignment(Hh, Rd, hp, B.params, ml);
+    ml.ll = B.ll[p]; ml.llOn = B.llOn[p]; ml.llOff = B.llOff[p];
+    ml.offHap = B.offHap[p] != 0; ml.offHapHMQ = B.offHapHMQ[p] != 0;
+    if (!B.faster) ml.mLogBQ = B.mLogBQ[p];           // the device's serial sum (same order as the reference)
+    ml.hapIndelFilterCovered.clear();
+    {   // per haplotype-indel coverage flags of filterHaplotypes, in hap.indels map order (first nvI of the hap's list)
+        int i = 0;
+        for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
+            ml.hapIndelFilterCovered[it->first] = B.fcov[vb + i] != 0;
+    }
+}
+
+} // namespace
+
+// ---------------- WindowLikelihoods: the lazy view ----------------
+size_t WindowLikelihoods::numHaps() const { return size_t(blk_->win_hap_off[w_ + 1] - blk_->win_hap_off[w_]); }
+size_t WindowLikelihoods::numReads() const { return size_t(blk_->win_read_off[w_ + 1] - blk_->win_read_off[w_]); }
+int64_t WindowLikelihoods::pair(size_t h, size_t r) const { return blk_->pair_off[w_] + int64_t(h) * int64_t(numReads()) + int64_t(r); }
+double WindowLikelihoods::ll(size_t h, size_t r) const { return blk_->ll[pair(h, r)]; }
+double WindowLikelihoods::llOn(size_t h, size_t r) const { return blk_->llOn[pair(h, r)]; }
+double WindowLikelihoods::llOff(size_t h, size_t r) const { return blk_->llOff[pair(h, r)]; }
+double WindowLikelihoods::mLogBQ(size_t h, size_t r) const { return blk_->mLogBQ[pair(h, r)]; }
+bool WindowLikelihoods::offHap(size_t h, size_t r) const { return blk_->offHap[pair(h, r)] != 0; }
+bool WindowLikelihoods::offHapHMQ(size_t h, size_t r) const { return blk_->offHapHMQ[pair(h, r)] != 0; }
+int WindowLikelihoods::numIndels(size_t h, size_t r) const { return blk_->numIndels[pair(h, r)]; }
+int WindowLikelihoods::numMismatch(size_t h, size_t r) const { return blk_->numMismatch[pair(h, r)]; }
+int WindowLikelihoods::nBQT(size_t h, size_t r) const { return blk_->nBQT[pair(h, r)]; }
+int WindowLikelihoods::nmmBQT(size_t h, size_t r) const { return blk_->nmmBQT[pair(h, r)]; }
+int WindowLikelihoods::nMMLeft(size_t h, size_t r) const { return blk_->nMMLeft[pair(h, r)]; }
+int WindowLikelihoods::nMMRight(size_t h, size_t r) const { return blk_->nMMRight[pair(h, r)]; }
+int WindowLikelihoods::firstBase(size_t h, size_t r) const { return blk_->firstBase[pair(h, r)]; }
+int WindowLikelihoods::lastBase(size_t h, size_t r) const { return blk_->lastBase[pair(h, r)]; }
+int WindowLikelihoods::onHap(size_t r) const { return blk_->onHap[size_t(blk_->win_read_off[w_]) + r]; }
+
+// slot of the haplotype's variant `key` in the per-pair flag list: hap.indels in map order, then hap.snps (-1: no such variant)
+int WindowLikelihoods::varSlot(size_t h, int key, bool snp) const
+{
+    const Haplotype &H = (*haps_)[h];
+    const std::map<int, AlignedVariant> &m = snp ? H.snps : H.indels;
+    std::map<int, AlignedVariant>::const_iterator it = m.find(key);
+    if (it == m.end()) return -1;
+    return int(std::distance(m.begin(), it)) + (snp ? int(H.indels.size()) : 0);
+}
+
+static inline int64_t var_base(const BatchBlock &B, int w, size_t h, size_t r)
+{
+    const int g = B.win_hap_off[w] + int(h);
+    const int64_t Rn = B.win_read_off[w + 1] - B.win_read_off[w];
+    return B.vc_off[w] + int64_t(B.hap_var_off[g] - B.hap_var_off[B.win_hap_off[w]]) * Rn + int64_t(r) * (B.hap_var_off[g + 1] - B.hap_var_off[g]);
+}
+
+bool WindowLikelihoods::hapIndelCovered(size_t h, size_t r, int key) const
+{
+    const int s = varSlot(h, key, false);
+    return s >= 0 && blk_->vcov[var_base(*blk_, w_, h, r) + s] != 0;
+}
+bool WindowLikelihoods::hapSNPCovered(size_t h, size_t r, int key) const
+{
+    const int s = varSlot(h, key, true);
+    return s >= 0 && blk_->vcov[var_base(*blk_, w_, h, r) + s] != 0;
+}
+bool WindowLikelihoods::hapIndelFilterCovered(size_t h, size_t r, int key) const
+{
+    const int s = varSlot(h, key, false);
+    return s >= 0 && blk_->fcov[var_base(*blk_, w_, h, r) + s] != 0;
+}
+
+MLAlignment WindowLikelihoods::get(size_t h, size_t r) const
+{
+    MLAlignment ml;
+    if (blk_->has_hpos) { fill_record(*blk_, w_, h, r, (*haps_)[h], (*reads_)[r], ml); return ml; }
+    if (!full_) {                          // the batch kept no alignments: this window once more, with them
+        if (!eng_) throw std::string("WindowLikelihoods::get: batch was run without alignments and the engine is gone");
+        std::vector<WindowJob> one(1);
+        one[0].haps = haps_; one[0].reads = reads_; one[0].leftPos = leftPos_; one[0].rightPos = leftPos_ + 1;
+        const bool keep = eng_->keepAlignments_;
+        eng_->keepAlignments_ = true;
+        try { eng_->runBatch(one, blk_->faster); } catch (...) { eng_->keepAlignments_ = keep; throw; }
+        eng_->keepAlignments_ = keep;
+        if (!one[0].error.empty()) throw one[0].error;
+        full_ = one[0].result.blk_;
+    }
+    fill_record(*full_, 0, h, r, (*haps_)[h], (*reads_)[r], ml);
+    return ml;
+}
+
+void WindowLikelihoods::toLiks(std::vector<std::vector<MLAlignment> > &liks, std::vector<int> &onHapV) const
+{
+    const size_t H = numHaps(), Rn = numReads();
+    onHapV = std::vector<int>(Rn, 0);
+    liks = std::vector<std::vector<MLAlignment> >(H, std::vector<MLAlignment>(Rn));
+    for (size_t h = 0; h < H; h++)
+        for (size_t r = 0; r < Rn; r++) liks[h][r] = get(h, r);
+    for (size_t r = 0; r < Rn; r++) onHapV[r] = onHap(r);
+}
+
+// ---------------- LikelihoodEngine ----------------
 void LikelihoodEngine::computeLikelihoodsFaster(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
                                                 std::vector<std::vector<MLAlignment> > &liks, uint32_t leftPos,
                                                 uint32_t rightPos, std::vector<int> &onHap)
@@ -214,61 +463,44 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
 {
     const std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
     const int W = int(jobs.size());
-    // ---- pack (CSR) ----
-    std::vector<int32_t> win_hap_off(1, 0), win_read_off(1, 0), hap_seq_off(1, 0), hap_var_off(1, 0), hap_var, hap_var_flank, read_seq_off(1, 0);
-    std::vector<uint32_t> win_hap_start, read_start;
-    std::string hap_seq, read_seq;
-    std::vector<uint8_t> read_qidx, read_mqidx, read_flags, read_lib;
-    std::vector<int32_t> read_mate_pos, read_mate_len, lib_off(1, 0);
+    // The result block of an earlier call is reused when no view refers to it any more (its pages are mapped and, when
+    // pinned, registered with the device already); otherwise a new one is made and the old one lives on with its views.
+    for (int w = 0; w < W; w++) jobs[w].result = WindowLikelihoods();      // views of an earlier call held by these jobs
+    std::shared_ptr<BatchBlock> blk;
+    if (spare_ && spare_.use_count() == 1) blk = spare_; else blk = std::make_shared<BatchBlock>();
+    spare_ = blk;
+    if (!scratch_) scratch_ = std::make_shared<PackScratch>();
+    BatchBlock &B = *blk;
+    PackScratch &S = *scratch_;
+    B.W = W; B.faster = faster; B.params = params;
+    bool any_eager = false;
+    for (int w = 0; w < W; w++) if (jobs[w].liks) any_eager = true;
+    B.has_hpos = keepAlignments_ || any_eager;
+
+    // ---- pack (CSR), pass 1: sizes and offsets (serial, O(haplotypes + reads)) ----
+    const bool with_mates = params.mapUnmappedReads && !faster;
+    B.win_hap_off.assign(1, 0); B.win_read_off.assign(1, 0); B.hap_var_off.assign(1, 0); B.read_seq_off.assign(1, 0);
+    S.hap_seq_off.assign(1, 0);
+    std::vector<int32_t> lib_off(1, 0);
     std::vector<double> lib_prob, lib_p95;
     std::map<const Library *, int> lib_index;
-    const bool with_mates = params.mapUnmappedReads && !faster;
-    std::map<double, int> qmap, mqmap;
-    std::vector<double> qtab, mqtab;
+    int64_t n_hap_bases = 0, n_read_bases = 0;
+    if (with_mates) S.read_lib.clear();
     for (int w = 0; w < W; w++) {
         WindowJob &J = jobs[w];
         J.error.clear();
-        win_hap_start.push_back(J.leftPos);
         for (size_t h = 0; h < J.haps->size(); h++) {
             const Haplotype &H = (*J.haps)[h];
-            hap_seq += H.seq;
-            hap_seq_off.push_back(int32_t(hap_seq.size()));
-            for (std::map<int, AlignedVariant>::const_iterator it = H.indels.begin(); it != H.indels.end(); ++it) {
-                hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
-                hap_var_flank.push_back(it->second.getLeftFlankRead()); hap_var_flank.push_back(it->second.getRightFlankRead());
-                hap_var_flank.push_back(it->second.getType() == AlignedVariant::DEL ? 1 : it->second.getType() == AlignedVariant::INS ? 2 : 0);
-            }
-            for (std::map<int, AlignedVariant>::const_iterator it = H.snps.begin(); it != H.snps.end(); ++it) {
-                hap_var.push_back(it->second.getStartRead()); hap_var.push_back(it->second.getEndRead());
-                hap_var_flank.push_back(0); hap_var_flank.push_back(0); hap_var_flank.push_back(0);
-            }
-            hap_var_off.push_back(int32_t(hap_var.size() / 2));
+            n_hap_bases += int64_t(H.seq.size());
+            S.hap_seq_off.push_back(int32_t(n_hap_bases));
+            B.hap_var_off.push_back(B.hap_var_off.back() + int32_t(H.indels.size() + H.snps.size()));
         }
-        win_hap_off.push_back(win_hap_off.back() + int32_t(J.haps->size()));
+        B.win_hap_off.push_back(B.win_hap_off.back() + int32_t(J.haps->size()));
         for (size_t r = 0; r < J.reads->size(); r++) {
             const Read &R = (*J.reads)[r];
             if (R.qual.size() != R.size()) throw std::string("Read: qual and seq differ in length");
-            read_seq += R.seq.seq;
-            read_seq_off.push_back(int32_t(read_seq.size()));
-            double lastq = -1.0;
-            int lastidx = 0;
-            for (size_t b = 0; b < R.qual.size(); b++) {
-                if (R.qual[b] != lastq) {                 // runs of equal qualities skip the map
-                    std::map<double, int>::iterator it = qmap.find(R.qual[b]);
-                    if (it == qmap.end()) { it = qmap.insert(std::make_pair(R.qual[b], int(qtab.size()))).first; qtab.push_back(R.qual[b]); }
-                    if (it->second > 255) throw std::string("more than 256 distinct base qualities in one batch");
-                    lastq = R.qual[b]; lastidx = it->second;
-                }
-                read_qidx.push_back(uint8_t(lastidx));
-            }
-            std::map<double, int>::iterator it = mqmap.find(R.mapQual);
-            if (it == mqmap.end()) { it = mqmap.insert(std::make_pair(R.mapQual, int(mqtab.size()))).first; mqtab.push_back(R.mapQual); }
-            if (it->second > 255) throw std::string("more than 256 distinct mapping qualities in one batch");
-            read_mqidx.push_back(uint8_t(it->second));
-            read_start.push_back(uint32_t(R.posStat.first));      // uint32_t(read.posStat.first), ObservationModelFB.cpp:52
-            read_flags.push_back(uint8_t((R.isUnmapped() ? DD_READ_UNMAPPED : 0) | (R.isPaired() ? DD_READ_PAIRED : 0) |
-                                         (R.mateIsUnmapped() ? DD_READ_MATE_UNMAPPED : 0) | (R.mateIsReverse() ? DD_READ_MATE_REVERSE : 0) |
-                                         (R.mateSameTid ? DD_READ_MATE_SAME_TID : 0)));
+            n_read_bases += int64_t(R.size());
+            B.read_seq_off.push_back(int32_t(n_read_bases));
             if (with_mates) {
                 int li = 0;
                 if (R.isPaired()) {                      // the reference dereferences the library of paired reads only (:279-289)
@@ -283,148 +515,175 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
                     }
                     li = lt->second;
                 }
-                read_lib.push_back(uint8_t(li));
-                read_mate_pos.push_back(R.matePos);
-                read_mate_len.push_back(R.isPaired() ? R.mateLen : -1);
+                S.read_lib.push_back(uint8_t(li));
             }
         }
-        win_read_off.push_back(win_read_off.back() + int32_t(J.reads->size()));
+        B.win_read_off.push_back(B.win_read_off.back() + int32_t(J.reads->size()));
+        if (n_hap_bases > 0x7fffffffLL || n_read_bases > 0x7fffffffLL)
+            throw std::string("batch too large: more than 2^31 haplotype or read bases (split the windows over several calls)");
     }
-    dd_batch B;
-    memset(&B, 0, sizeof(B));
-    B.n_windows = W;
-    B.win_hap_off = win_hap_off.data(); B.win_read_off = win_read_off.data(); B.win_hap_start = win_hap_start.data();
-    B.hap_seq_off = hap_seq_off.data(); B.hap_seq = hap_seq.data(); B.hap_var_off = hap_var_off.data();
-    B.hap_var = hap_var.empty() ? NULL : hap_var.data();
-    B.hap_var_flank = hap_var_flank.empty() ? NULL : hap_var_flank.data();
-    B.read_seq_off = read_seq_off.data(); B.read_seq = read_seq.data(); B.read_qidx = read_qidx.data();
-    B.read_mqidx = read_mqidx.data(); B.read_start = read_start.data(); B.read_flags = read_flags.data();
-    B.n_qual = int(qtab.size()); B.qual_table = qtab.data(); B.n_mapq = int(mqtab.size()); B.mapq_table = mqtab.data();
+    const size_t n_haps = size_t(B.win_hap_off[W]), n_reads = size_t(B.win_read_off[W]), n_var = size_t(B.hap_var_off[n_haps]);
+    S.win_hap_start.resize(size_t(W)); S.hap_seq.resize(size_t(n_hap_bases) + 1); S.read_seq.resize(size_t(n_read_bases) + 1);
+    S.read_qidx.resize(size_t(n_read_bases) + 1); S.read_mqidx.resize(n_reads + 1); S.read_start.resize(n_reads + 1);
+    S.read_flags.resize(n_reads + 1); S.hap_var.resize(2 * n_var + 1); S.hap_var_flank.resize(3 * n_var + 1);
+    if (with_mates) { S.read_mate_pos.resize(n_reads + 1); S.read_mate_len.resize(n_reads + 1); }
+
+    // ---- pass 2: the bytes, windows in parallel ----
+    ValueTable qtab, mqtab;
+    std::atomic<int> overflow(0);
+    const unsigned nthr = pick_threads(hostThreads_, W);
+    {
+        auto pack_window = [&](int w, ValueCache &qc, ValueCache &mc) {
+            const WindowJob &J = jobs[w];
+            S.win_hap_start[size_t(w)] = J.leftPos;
+            for (size_t h = 0; h < J.haps->size(); h++) {
+                const Haplotype &H = (*J.haps)[h];
+                const int g = B.win_hap_off[w] + int(h);
+                memcpy(S.hap_seq.data() + S.hap_seq_off[size_t(g)], H.seq.data(), H.seq.size());
+                int32_t *hv = S.hap_var.data() + 2 * size_t(B.hap_var_off[g]);
+                int32_t *hf = S.hap_var_flank.data() + 3 * size_t(B.hap_var_off[g]);
+                for (std::map<int, AlignedVariant>::const_iterator it = H.indels.begin(); it != H.indels.end(); ++it) {
+                    *hv++ = it->second.getStartRead(); *hv++ = it->second.getEndRead();
+                    *hf++ = it->second.getLeftFlankRead(); *hf++ = it->second.getRightFlankRead();
+                    *hf++ = it->second.getType() == AlignedVariant::DEL ? 1 : it->second.getType() == AlignedVariant::INS ? 2 : 0;
+                }
+                for (std::map<int, AlignedVariant>::const_iterator it = H.snps.begin(); it != H.snps.end(); ++it) {
+                    *hv++ = it->second.getStartRead(); *hv++ = it->second.getEndRead();
+                    *hf++ = 0; *hf++ = 0; *hf++ = 0;
+                }
+            }
+            for (size_t r = 0; r < J.reads->size(); r++) {
+                const Read &R = (*J.reads)[r];
+                const size_t q = size_t(B.win_read_off[w]) + r;
+                const size_t so = size_t(B.read_seq_off[q]);
+                memcpy(S.read_seq.data() + so, R.seq.seq.data(), R.size());
+                uint8_t *qi = S.read_qidx.data() + so;
+                double lastq = -1.0;
+                int lastidx = 0;
+                for (size_t b = 0; b < R.qual.size(); b++) {
+                    if (R.qual[b] != lastq) {                 // runs of equal qualities skip the lookup
+                        const int idx = qc.get(R.qual[b], qtab);
+                        if (idx < 0) { overflow.store(1); return; }
+                        lastq = R.qual[b]; lastidx = idx;
+                    }
+                    qi[b] = uint8_t(lastidx);
+                }
+                const int mi = mc.get(R.mapQual, mqtab);
+                if (mi < 0) { overflow.store(2); return; }
+                S.read_mqidx[q] = uint8_t(mi);
+                S.read_start[q] = uint32_t(R.posStat.first);      // uint32_t(read.posStat.first), ObservationModelFB.cpp:52
+                S.read_flags[q] = uint8_t((R.isUnmapped() ? DD_READ_UNMAPPED : 0) | (R.isPaired() ? DD_READ_PAIRED : 0) |
+                                          (R.mateIsUnmapped() ? DD_READ_MATE_UNMAPPED : 0) | (R.mateIsReverse() ? DD_READ_MATE_REVERSE : 0) |
+                                          (R.mateSameTid ? DD_READ_MATE_SAME_TID : 0));
+                if (with_mates) {
+                    S.read_mate_pos[q] = R.matePos;
+                    S.read_mate_len[q] = R.isPaired() ? R.mateLen : -1;
+                }
+            }
+        };
+        if (nthr <= 1 || W < 8) {
+            ValueCache qc, mc;
+            for (int w = 0; w < W; w++) pack_window(w, qc, mc);
+        } else {
+            std::atomic<int> next(0);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nthr; t++)
+                pool.push_back(std::thread([&]() {
+                    ValueCache qc, mc;
+                    for (int w0 = next.fetch_add(8); w0 < W; w0 = next.fetch_add(8))
+                        for (int w = w0; w < W && w < w0 + 8; w++) pack_window(w, qc, mc);
+                }));
+            for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+        }
+        if (overflow.load() == 1) throw std::string("more than 256 distinct base qualities in one batch");
+        if (overflow.load() == 2) throw std::string("more than 256 distinct mapping qualities in one batch");
+    }
+    dd_batch Bt;
+    memset(&Bt, 0, sizeof(Bt));
+    Bt.n_windows = W;
+    Bt.win_hap_off = B.win_hap_off.data(); Bt.win_read_off = B.win_read_off.data(); Bt.win_hap_start = S.win_hap_start.data();
+    Bt.hap_seq_off = S.hap_seq_off.data(); Bt.hap_seq = S.hap_seq.data(); Bt.hap_var_off = B.hap_var_off.data();
+    Bt.hap_var = n_var ? S.hap_var.data() : NULL;
+    Bt.hap_var_flank = n_var ? S.hap_var_flank.data() : NULL;
+    Bt.read_seq_off = B.read_seq_off.data(); Bt.read_seq = S.read_seq.data(); Bt.read_qidx = S.read_qidx.data();
+    Bt.read_mqidx = S.read_mqidx.data(); Bt.read_start = S.read_start.data(); Bt.read_flags = S.read_flags.data();
+    double one_q = 0.5;
+    Bt.n_qual = int(qtab.tab.size()); Bt.qual_table = qtab.tab.empty() ? &one_q : qtab.tab.data();
+    Bt.n_mapq = int(mqtab.tab.size()); Bt.mapq_table = mqtab.tab.empty() ? &one_q : mqtab.tab.data();
     if (with_mates) {
         if (lib_p95.empty()) { lib_prob.push_back(1.0); lib_off.push_back(1); lib_p95.push_back(1.0); }   // no paired read: placeholder table
-        B.read_mate_pos = read_mate_pos.data(); B.read_mate_len = read_mate_len.data(); B.read_lib = read_lib.data();
-        B.n_libs = int(lib_p95.size()); B.lib_off = lib_off.data(); B.lib_prob = lib_prob.data(); B.lib_p95 = lib_p95.data();
+        Bt.read_mate_pos = S.read_mate_pos.data(); Bt.read_mate_len = S.read_mate_len.data(); Bt.read_lib = S.read_lib.data();
+        Bt.n_libs = int(lib_p95.size()); Bt.lib_off = lib_off.data(); Bt.lib_prob = lib_prob.data(); Bt.lib_p95 = lib_p95.data();
     }
 
     dd_sizes sz;
-    if (dd_batch_sizes(&B, &sz) != DD_SUCCESS) throw std::string(dd_last_error());
-    std::vector<int64_t> pair_off(W + 1), hpos_off(W + 1), vc_off(W + 1);
-    dd_batch_offsets(&B, pair_off.data(), hpos_off.data(), vc_off.data());
+    if (dd_batch_sizes(&Bt, &sz) != DD_SUCCESS) throw std::string(dd_last_error());
+    B.pair_off.resize(size_t(W) + 1); B.hpos_off.resize(size_t(W) + 1); B.vc_off.resize(size_t(W) + 1);
+    dd_batch_offsets(&Bt, B.pair_off.data(), B.hpos_off.data(), B.vc_off.data());
 
-    std::vector<double> ll(sz.n_pairs), llOn(sz.n_pairs), llOff(sz.n_pairs), mLogBQ(sz.n_pairs);
-    std::vector<uint8_t> offHap(sz.n_pairs), offHapHMQ(sz.n_pairs), onHapV(sz.n_reads ? sz.n_reads : 1);
-    std::vector<int16_t> hpos(sz.hpos_len ? sz.hpos_len : 1);
-    std::vector<int16_t> numIndels(sz.n_pairs), numMismatch(sz.n_pairs), nBQT(sz.n_pairs), nmmBQT(sz.n_pairs), nMMLeft(sz.n_pairs),
-        nMMRight(sz.n_pairs), firstBase(sz.n_pairs), lastBase(sz.n_pairs);
-    std::vector<int32_t> status(sz.n_pairs);
-    std::vector<uint8_t> fcov(sz.var_cov_len ? sz.var_cov_len : 1), vcov(sz.var_cov_len ? sz.var_cov_len : 1);
+    const size_t np = size_t(sz.n_pairs) + 1;
     dd_result Rz;
     memset(&Rz, 0, sizeof(Rz));
-    Rz.ll = ll.data(); Rz.llOn = llOn.data(); Rz.llOff = llOff.data(); Rz.mLogBQ = mLogBQ.data();
-    Rz.offHap = offHap.data(); Rz.offHapHMQ = offHapHMQ.data(); Rz.hpos = hpos.data(); Rz.status = status.data();
-    Rz.numIndels = numIndels.data(); Rz.numMismatch = numMismatch.data(); Rz.nBQT = nBQT.data(); Rz.nmmBQT = nmmBQT.data();
-    Rz.nMMLeft = nMMLeft.data(); Rz.nMMRight = nMMRight.data(); Rz.firstBase = firstBase.data(); Rz.lastBase = lastBase.data();
-    Rz.onHap = onHapV.data();
-    Rz.var_fcov = fcov.data(); Rz.var_covered = vcov.data();
+    Rz.ll = B.ll.reserve(np); Rz.llOn = B.llOn.reserve(np); Rz.llOff = B.llOff.reserve(np); Rz.mLogBQ = B.mLogBQ.reserve(np);
+    Rz.offHap = B.offHap.reserve(np); Rz.offHapHMQ = B.offHapHMQ.reserve(np); Rz.status = B.status.reserve(np);
+    Rz.numIndels = B.numIndels.reserve(np); Rz.numMismatch = B.numMismatch.reserve(np); Rz.nBQT = B.nBQT.reserve(np);
+    Rz.nmmBQT = B.nmmBQT.reserve(np); Rz.nMMLeft = B.nMMLeft.reserve(np); Rz.nMMRight = B.nMMRight.reserve(np);
+    Rz.firstBase = B.firstBase.reserve(np); Rz.lastBase = B.lastBase.reserve(np);
+    Rz.onHap = B.onHap.reserve(size_t(sz.n_reads) + 1);
+    Rz.var_fcov = B.fcov.reserve(size_t(sz.var_cov_len) + 1); Rz.var_covered = B.vcov.reserve(size_t(sz.var_cov_len) + 1);
+    if (B.has_hpos) Rz.hpos = B.hpos.reserve(size_t(sz.hpos_len) + 1);
     dd_params P = to_abi(params);
     if (faster) P.mapUnmappedReads = 0;                 // ObservationModelS has no insert-size prior
     const std::chrono::steady_clock::time_point t_packed = std::chrono::steady_clock::now();
     if (sz.n_pairs > 0) {
-        const int rc = faster ? dd_compute_likelihoods_faster(&P, &B, &Rz, device_) : dd_compute_likelihoods(&P, &B, &Rz, device_);
+        const int rc = faster ? dd_compute_likelihoods_faster(&P, &Bt, &Rz, device_) : dd_compute_likelihoods(&P, &Bt, &Rz, device_);
         if (rc != DD_SUCCESS) throw std::string(faster ? "dd_compute_likelihoods_faster: " : "dd_compute_likelihoods: ") + dd_last_error();
+    } else {
+        for (int64_t q = 0; q < sz.n_reads; q++) B.onHap[size_t(q)] = 0;
     }
 
     const std::chrono::steady_clock::time_point t_device = std::chrono::steady_clock::now();
-    // ---- unpack into liks[hidx][r] / onHap: windows are independent, so a few host threads share them ----
-    // Per pair the device already delivers every counter of the record; the variant maps and the `align` string need the
-    // per-base walk (rebuildAlignment) only when the read shows an indel or differs from the haplotype segment it sits on.
-    auto unpack_window = [&](int w) {
+    // ---- per window: the error the reference's loop would have stopped at (first pair in liks[h][r] order that is not OK),
+    // the lazy view, and — for jobs that bring the reference's containers — every record ----
+    const std::shared_ptr<const BatchBlock> cblk = blk;
+    auto finish_window = [&](int w) {
         WindowJob &J = jobs[w];
         const size_t H = J.haps->size(), Rn = J.reads->size();
-        *J.onHap = std::vector<int>(Rn, 0);                                              // DInDel.cpp:1710
-        *J.liks = std::vector<std::vector<MLAlignment> >(H, std::vector<MLAlignment>(Rn)); // DInDel.cpp:1714
-        const int r0 = win_read_off[w];
-        const int64_t SL = int64_t(read_seq_off[win_read_off[w + 1]]) - read_seq_off[r0];
+        const bool eager = J.liks != NULL;
+        if (J.onHap) *J.onHap = std::vector<int>(Rn, 0);                                                        // DInDel.cpp:1710
+        if (eager) *J.liks = std::vector<std::vector<MLAlignment> >(H, std::vector<MLAlignment>(Rn));           // DInDel.cpp:1714
         for (size_t h = 0; h < H && J.error.empty(); h++) {
-            const Haplotype &Hh = (*J.haps)[h];
-            const int Hs = int(Hh.size());
-            const int g = win_hap_off[w] + int(h);
-            const int nv = hap_var_off[g + 1] - hap_var_off[g];
             for (size_t r = 0; r < Rn; r++) {
-                const int64_t p = pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
-                if (status[p] == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47, Faster.cpp:47
-                if (status[p] == DD_PAIR_UNSUPPORTED) {      // this window only; the caller skips it like a window that threw (DInDel.cpp:1369-1374)
+                const int64_t p = B.pair_off[w] + int64_t(h) * int64_t(Rn) + int64_t(r);
+                const int st = B.status[size_t(p)];
+                if (st == DD_PAIR_HAPSIZE) { J.error = "hapSize error."; break; }   // ObservationModelFB.cpp:47, Faster.cpp:47
+                if (st == DD_PAIR_UNSUPPORTED) {      // this window only; the caller skips it like a window that threw (DInDel.cpp:1369-1374)
                     J.error = "window outside the GPU kernel limits (haplotype > 766 bp, read > 1024 bp or an empty sequence)";
                     break;
                 }
-                if (faster && status[p] != DD_PAIR_OK) { J.error = "HapHash string too short"; break; }   // Haplotype.hpp:341
-                MLAlignment &ml = (*J.liks)[h][r];
-                const Read &Rd = (*J.reads)[r];
-                const int L = int(Rd.size());
-                const int16_t *hp = hpos.data() + hpos_off[w] + int64_t(h) * SL + (read_seq_off[r0 + r] - read_seq_off[r0]);
-                const int64_t vb = vc_off[w] + int64_t(hap_var_off[g] - hap_var_off[win_hap_off[w]]) * int64_t(Rn) + int64_t(r) * nv;
-                bool plain = false;                       // gap-free, mismatch-free placement: nothing to list
-                if (!faster && numIndels[p] == 0) {
-                    if (firstBase[p] < 0) plain = true;   // no base on the haplotype
-                    else {
-                        int b0 = 0;
-                        while (b0 < L && hp[b0] < 0) b0++;
-                        const int n = lastBase[p] - firstBase[p] + 1;
-                        plain = b0 + n <= L && hp[b0] == firstBase[p] &&
-                                memcmp(Rd.seq.seq.data() + b0, Hh.seq.data() + firstBase[p], size_t(n)) == 0;
-                    }
-                }
-                if (plain) {
-                    ml.align = std::string(size_t(Hs), 'R');
-                    ml.hpos.assign(hp, hp + L);
-                    ml.firstBase = firstBase[p]; ml.lastBase = lastBase[p];
-                    ml.numIndels = 0; ml.numMismatch = numMismatch[p]; ml.nBQT = nBQT[p]; ml.nmmBQT = nmmBQT[p];
-                    ml.nMMLeft = nMMLeft[p]; ml.nMMRight = nMMRight[p];
-                    int i = 0;
-                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
-                        ml.hapIndelCovered[it->first] = vcov[vb + i] != 0;
-                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.snps.begin(); it != Hh.snps.end(); ++it, ++i)
-                        ml.hapSNPCovered[it->first] = vcov[vb + i] != 0;
-                } else if (faster) rebuildAlignmentFaster(Hh, Rd, hp, params, ml);
-                else rebuildAlignment(Hh, Rd, hp, params, ml);
-                ml.ll = ll[p]; ml.llOn = llOn[p]; ml.llOff = llOff[p];
-                ml.offHap = offHap[p] != 0; ml.offHapHMQ = offHapHMQ[p] != 0;
-                if (!faster) ml.mLogBQ = mLogBQ[p];           // the device's serial sum (same order as the reference)
-                {   // per haplotype-indel coverage flags of filterHaplotypes, in hap.indels map order (first nvI of the hap's list)
-                    int i = 0;
-                    for (std::map<int, AlignedVariant>::const_iterator it = Hh.indels.begin(); it != Hh.indels.end(); ++it, ++i)
-                        ml.hapIndelFilterCovered[it->first] = fcov[vb + i] != 0;
-                }
-                if (!ml.offHapHMQ) (*J.onHap)[r] = 1;                                     // DInDel.cpp:1720
+                if (faster && st != DD_PAIR_OK) { J.error = "HapHash string too short"; break; }   // Haplotype.hpp:341
+                if (eager) fill_record(B, w, h, r, (*J.haps)[h], (*J.reads)[r], (*J.liks)[h][r]);
+                if (J.onHap && !B.offHapHMQ[size_t(p)]) (*J.onHap)[r] = 1;                // DInDel.cpp:1720
                 if (faster) continue;                                                     // computeLikelihoodsFaster has no ll checks
-                if (status[p] == DD_PAIR_LLPOS) {                                         // DInDel.cpp:1722-1731
+                if (st == DD_PAIR_LLPOS) {                                                // DInDel.cpp:1722-1731
                     if (throwOnPositive_) { J.error = "Likelihood>0"; break; }
                     std::cout << "hidx: " << h << " r: " << r << std::endl;
                     std::cerr << "Likelihood>0" << std::endl;
                     exit(1);
                 }
-                if (status[p] == DD_PAIR_NAN) {                                           // DInDel.cpp:1732-1735
+                if (st == DD_PAIR_NAN) {                                                  // DInDel.cpp:1732-1735
                     std::cout << "NAN/Inf error" << std::endl;
                     J.error = "Nan detected";
                     break;
                 }
             }
         }
+        if (J.error.empty()) {
+            J.result.blk_ = cblk; J.result.w_ = w; J.result.haps_ = J.haps; J.result.reads_ = J.reads;
+            J.result.leftPos_ = J.leftPos; J.result.eng_ = this;
+        }
     };
-    unsigned nthr = std::thread::hardware_concurrency();
-    if (nthr > 16) nthr = 16;
-    if (nthr < 1) nthr = 1;
-    if (hostThreads_ > 0) nthr = unsigned(hostThreads_);
-    if (nthr > unsigned(W)) nthr = unsigned(W > 0 ? W : 1);
-    if (nthr <= 1) {
-        for (int w = 0; w < W; w++) unpack_window(w);
-    } else {
-        std::atomic<int> next(0);
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthr; t++)
-            pool.push_back(std::thread([&]() { for (int w = next++; w < W; w = next++) unpack_window(w); }));
-        for (size_t t = 0; t < pool.size(); t++) pool[t].join();
-    }
+    parallel_windows(W, pick_threads(hostThreads_, W), 4, finish_window);
     const std::chrono::steady_clock::time_point t_end = std::chrono::steady_clock::now();
     lastPackSeconds = std::chrono::duration<double>(t_packed - t_start).count();
     lastDeviceSeconds = std::chrono::duration<double>(t_device - t_packed).count();

@@ -8,32 +8,93 @@
 //   * haplotype shorter than maxLengthDel  -> throws std::string("hapSize error.")   (ObservationModelFB.cpp:47)
 //   * NaN / Inf log-likelihood             -> throws std::string("Nan detected")     (DInDel.cpp:1732-1735)
 //   * log-likelihood > 0.1                 -> "Likelihood>0" on stderr, exit(1)      (DInDel.cpp:1722-1731)
+//                                             (setThrowOnPositiveLikelihood(true) turns the exit into a throw)
 //   * window shape outside the kernel limits (haplotype > 766 bp, read > 1024 bp, empty sequence; no reference
 //     counterpart) -> throws std::string("window outside the GPU kernel limits ...") for THAT window only
-//                                             (setThrowOnPositiveLikelihood(true) turns the exit into a throw)
 // All arithmetic runs on the GPU through the C ABI (include/dindel_hmm.h); this class only packs the
-// windows, calls dd_compute_likelihoods and rebuilds the MLAlignment records (variant strings from hpos).
+// windows, calls dd_compute_likelihoods and hands the records back.
+//
+// Two ways to receive a batch's records:
+//   * eager  — WindowJob::liks / onHap point at the reference's containers: every MLAlignment (five std::map's, two
+//              strings, a vector) is rebuilt.  The literal drop-in; the host spends ~0.1 us per read base on it.
+//   * lazy   — WindowJob::liks == NULL: the job's WindowLikelihoods view exposes every scalar of every record straight from
+//              the batch's result block (what the reductions of DInDel.cpp:2933-3660 read: ll, offHap, numIndels, the QC
+//              counters, the covered flags) and builds a full MLAlignment only for the pairs a consumer asks for (get()).
 #ifndef DINDEL_COMPUTE_LIKELIHOODS_HPP
 #define DINDEL_COMPUTE_LIKELIHOODS_HPP
 #include <cstdint>
+#include <memory>
 #include <vector>
 #include "dindel_types.hpp"
 
 namespace dindel {
 
+class LikelihoodEngine;
+struct BatchBlock;                       // flat result arrays of one batch call (compute_likelihoods.cpp)
+struct PackScratch;                      // flat input arrays of one batch call
+
+// Read-only view of one window's records inside a batch's result block.  Cheap to copy; keeps the block alive.
+class WindowLikelihoods {
+public:
+    WindowLikelihoods() : w_(-1), haps_(NULL), reads_(NULL), leftPos_(0), eng_(NULL) {}
+    bool valid() const { return w_ >= 0 && bool(blk_); }
+    size_t numHaps() const;
+    size_t numReads() const;
+    // the scalars of liks[h][r] (MLAlignment.hpp:35-75)
+    double ll(size_t h, size_t r) const;
+    double llOn(size_t h, size_t r) const;
+    double llOff(size_t h, size_t r) const;
+    double mLogBQ(size_t h, size_t r) const;
+    bool offHap(size_t h, size_t r) const;
+    bool offHapHMQ(size_t h, size_t r) const;
+    int numIndels(size_t h, size_t r) const;      // == liks[h][r].indels.size() for the main model (one key per event)
+    int numMismatch(size_t h, size_t r) const;
+    int nBQT(size_t h, size_t r) const;
+    int nmmBQT(size_t h, size_t r) const;
+    int nMMLeft(size_t h, size_t r) const;
+    int nMMRight(size_t h, size_t r) const;
+    int firstBase(size_t h, size_t r) const;
+    int lastBase(size_t h, size_t r) const;
+    int onHap(size_t r) const;                    // DInDel.cpp:1720
+    // liks[h][r].hapIndelCovered[key] / hapSNPCovered[key] (false when the haplotype has no such variant, like the
+    // reference's find()-then-test at DInDel.cpp:3158, :3539) and the filterHaplotypes coverage flag of a haplotype indel
+    bool hapIndelCovered(size_t h, size_t r, int key) const;
+    bool hapSNPCovered(size_t h, size_t r, int key) const;
+    bool hapIndelFilterCovered(size_t h, size_t r, int key) const;
+    // the full record of one pair, built on demand (variant maps, align string, hpos).  If the batch was run without
+    // alignments (setKeepAlignments(false)) the window is recomputed once through the engine and cached.
+    MLAlignment get(size_t h, size_t r) const;
+    // all records, as the eager path fills them
+    void toLiks(std::vector<std::vector<MLAlignment> > &liks, std::vector<int> &onHap) const;
+
+private:
+    friend class LikelihoodEngine;
+    int64_t pair(size_t h, size_t r) const;
+    int varSlot(size_t h, int key, bool snp) const;
+    std::shared_ptr<const BatchBlock> blk_;
+    mutable std::shared_ptr<const BatchBlock> full_;   // recomputed one-window block (no-alignment batches)
+    int w_;
+    const std::vector<Haplotype> *haps_;
+    const std::vector<Read> *reads_;
+    uint32_t leftPos_;
+    LikelihoodEngine *eng_;
+};
+
 struct WindowJob {                      // one call of the reference's computeLikelihoods
+    WindowJob() : haps(NULL), reads(NULL), leftPos(0), rightPos(0), liks(NULL), onHap(NULL) {}
     const std::vector<Haplotype> *haps;
     const std::vector<Read> *reads;
     uint32_t leftPos, rightPos;
-    std::vector<std::vector<MLAlignment> > *liks;   // OUT
-    std::vector<int> *onHap;                        // OUT
+    std::vector<std::vector<MLAlignment> > *liks;   // OUT (eager); NULL = lazy: use `result`
+    std::vector<int> *onHap;                        // OUT (eager); may be NULL
+    WindowLikelihoods result;                       // OUT: always set (unless the window has an error)
     std::string error;                              // OUT: empty, or the string the reference would have thrown
 };
 
 class LikelihoodEngine {
 public:
     explicit LikelihoodEngine(const ObservationModelParameters &obsParams, int device = 0)
-        : params(obsParams), device_(device), throwOnPositive_(false), hostThreads_(0) {}
+        : params(obsParams), device_(device), throwOnPositive_(false), hostThreads_(0), keepAlignments_(true) {}
 
     ObservationModelParameters params;   // the reference passes this->params.obsParams implicitly (DInDel.cpp:1718)
 
@@ -55,10 +116,13 @@ public:
     void computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs);
 
     void setThrowOnPositiveLikelihood(bool v) { throwOnPositive_ = v; }
-    // host threads rebuilding the MLAlignment records of a batch (0 = min(16, hardware threads))
+    // host threads packing the windows / rebuilding eager records (0 = min(16, hardware threads))
     void setHostThreads(int n) { hostThreads_ = n; }
+    // false: the per-base alignments (hpos, 45 % of the result bytes) stay on the device side of the call; lazy views
+    // recompute a window on the first get().  Scalars, covered flags and onHap are always delivered.
+    void setKeepAlignments(bool v) { keepAlignments_ = v; }
 
-    // wall time of the last batch call's three stages (tools/host_adapter_bench.cpp)
+    // wall time of the last batch call's three stages (tools/host_adapter_bench.cpp, bench.py)
     double lastPackSeconds = 0.0, lastDeviceSeconds = 0.0, lastUnpackSeconds = 0.0;
 
     // ObservationModelFBMax::reportVariants (ObservationModelFB.cpp:1351-1475) from the device's hpos: fills
@@ -66,17 +130,20 @@ public:
     static void rebuildAlignment(const Haplotype &hap, const Read &read, const int16_t *hpos,
                                  const ObservationModelParameters &p, MLAlignment &ml);
 
-    // ObservationModelS::reportVariants (Faster.cpp:579-681) from the device's hpos.  The position of an insertion is
-    // one past the last on-haplotype base before it (Faster.cpp:552-571); bases the model parks on the last haplotype
-    // base because they lie right of the haplotype are indistinguishable from it in hpos and count as that base here.
+    // ObservationModelS::reportVariants (Faster.cpp:579-681) from the device's hpos (inserted bases carry the key the
+    // model assigned them, Faster.cpp:552-571, so overhanging bases parked on the last haplotype base do not confuse it).
     static void rebuildAlignmentFaster(const Haplotype &hap, const Read &read, const int16_t *hpos,
                                        const ObservationModelParameters &p, MLAlignment &ml);
 
 private:
+    friend class WindowLikelihoods;
     void runBatch(std::vector<WindowJob> &jobs, bool faster);
     int device_;
     bool throwOnPositive_;
     int hostThreads_;
+    bool keepAlignments_;
+    std::shared_ptr<BatchBlock> spare_;      // result block of an earlier call that nobody references any more: reused (warm pages)
+    std::shared_ptr<PackScratch> scratch_;   // the packed inputs' buffers, reused between calls
 };
 
 } // namespace dindel

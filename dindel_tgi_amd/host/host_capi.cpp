@@ -1,5 +1,6 @@
 // host_capi.cpp — small extern "C" hooks so the pytest suite can drive the C++ host adapter
 // (LikelihoodEngine) through ctypes.  Not part of the drop-in boundary.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -295,6 +296,189 @@ int ddh_filter_window_json(const char *haps_nl, const int *hap_vars, const char 
         return emit(os.str(), out, cap);
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+
+
+// ---- batch hooks: LikelihoodEngine::computeLikelihoodsBatch over several windows ----
+namespace {
+struct HookWindows {
+    std::vector<std::vector<Haplotype> > haps;
+    std::vector<std::vector<Read> > reads;
+    std::vector<uint32_t> left;
+};
+
+// windows as flat arrays: n_haps[W], n_reads[W], '\n'-joined haplotypes and reads (an empty line = an empty sequence),
+// one quality per read base, mapq / start / unmapped per read, leftPos per window
+void parse_windows(int W, const int *n_haps, const int *n_reads, const char *haps_nl, const char *reads_nl, const double *quals,
+                   const double *mapq, const double *pos_first, const int *unmapped, const unsigned *leftPos, HookWindows &out)
+{
+    out.haps.resize(size_t(W)); out.reads.resize(size_t(W)); out.left.assign(leftPos, leftPos + W);
+    const char *hp = haps_nl, *rp = reads_nl;
+    size_t qoff = 0, ri = 0;
+    for (int w = 0; w < W; w++) {
+        for (int h = 0; h < n_haps[w]; h++) {
+            const char *e = strchr(hp, '\n');
+            const size_t n = e ? size_t(e - hp) : strlen(hp);
+            out.haps[size_t(w)].push_back(Haplotype(std::string(hp, n)));
+            hp += n + (e ? 1 : 0);
+        }
+        for (int r = 0; r < n_reads[w]; r++, ri++) {
+            const char *e = strchr(rp, '\n');
+            const size_t n = e ? size_t(e - rp) : strlen(rp);
+            Read R;
+            R.seq.seq = std::string(rp, n);
+            rp += n + (e ? 1 : 0);
+            R.qual.assign(quals + qoff, quals + qoff + n);
+            qoff += n;
+            R.mapQual = mapq[ri]; R.posStat.first = pos_first[ri]; R.unmapped = unmapped[ri] != 0;
+            out.reads[size_t(w)].push_back(R);
+        }
+    }
+}
+} // namespace
+
+// Runs the windows twice through computeLikelihoodsBatch — once eager (the reference's containers), once lazy (views; with
+// flags bit1 also without alignments kept) — and reports, per window, the error string and the lazy view's scalars, plus the
+// number of pairs whose lazy view (every scalar accessor and the full record from get()) differs from the eager record.
+// flags: bit0 = --faster model, bit1 = setKeepAlignments(false) for the lazy run.
+int ddh_batch_json(int W, const int *n_haps, const int *n_reads, const char *haps_nl, const char *reads_nl, const double *quals,
+                   const double *mapq, const double *pos_first, const int *unmapped, const unsigned *leftPos, const double *pd,
+                   const int *pi, int flags, int device, char *out, int cap)
+{
+    try {
+        HookWindows Wn;
+        parse_windows(W, n_haps, n_reads, haps_nl, reads_nl, quals, mapq, pos_first, unmapped, leftPos, Wn);
+        const bool faster = (flags & 1) != 0;
+        LikelihoodEngine eng(make_params(pd, pi), device);
+        eng.setThrowOnPositiveLikelihood(true);
+        std::vector<std::vector<std::vector<MLAlignment> > > liks(static_cast<size_t>(W));
+        std::vector<std::vector<int> > onHap(static_cast<size_t>(W));
+        std::vector<WindowJob> eager(static_cast<size_t>(W)), lazy(static_cast<size_t>(W));
+        for (int w = 0; w < W; w++) {
+            eager[size_t(w)].haps = lazy[size_t(w)].haps = &Wn.haps[size_t(w)];
+            eager[size_t(w)].reads = lazy[size_t(w)].reads = &Wn.reads[size_t(w)];
+            eager[size_t(w)].leftPos = lazy[size_t(w)].leftPos = Wn.left[size_t(w)];
+            eager[size_t(w)].rightPos = lazy[size_t(w)].rightPos = Wn.left[size_t(w)] + 1;
+            eager[size_t(w)].liks = &liks[size_t(w)]; eager[size_t(w)].onHap = &onHap[size_t(w)];
+        }
+        if (faster) eng.computeLikelihoodsFasterBatch(eager); else eng.computeLikelihoodsBatch(eager);
+        if (flags & 2) eng.setKeepAlignments(false);
+        if (faster) eng.computeLikelihoodsFasterBatch(lazy); else eng.computeLikelihoodsBatch(lazy);
+        long mismatch = 0;
+        std::ostringstream os;
+        os.precision(17);
+        os << "{\"windows\":[";
+        for (int w = 0; w < W; w++) {
+            const WindowJob &E = eager[size_t(w)], &Lz = lazy[size_t(w)];
+            os << (w ? "," : "") << "{\"error\":\"" << Lz.error << "\"";
+            if (E.error != Lz.error) mismatch++;
+            if (Lz.error.empty()) {
+                const WindowLikelihoods &V = Lz.result;
+                if (!V.valid() || V.numHaps() != Wn.haps[size_t(w)].size() || V.numReads() != Wn.reads[size_t(w)].size()) { mismatch++; os << "}"; continue; }
+                os << ",\"ll\":[";
+                for (size_t h = 0; h < V.numHaps(); h++)
+                    for (size_t r = 0; r < V.numReads(); r++) {
+                        os << ((h || r) ? "," : "") << V.ll(h, r);
+                        const MLAlignment &m = liks[size_t(w)][h][r];
+                        if (V.ll(h, r) != m.ll || V.llOn(h, r) != m.llOn || V.llOff(h, r) != m.llOff || V.offHap(h, r) != m.offHap ||
+                            V.offHapHMQ(h, r) != m.offHapHMQ || V.firstBase(h, r) != m.firstBase || V.lastBase(h, r) != m.lastBase)
+                            mismatch++;
+                        if (!faster && (V.mLogBQ(h, r) != m.mLogBQ || V.numIndels(h, r) != m.numIndels || V.numMismatch(h, r) != m.numMismatch ||
+                                        V.nBQT(h, r) != m.nBQT || V.nmmBQT(h, r) != m.nmmBQT || V.nMMLeft(h, r) != m.nMMLeft || V.nMMRight(h, r) != m.nMMRight))
+                            mismatch++;
+                        if (!faster && V.numIndels(h, r) != int(m.indels.size())) mismatch++;      // what DInDel.cpp:3529 reads
+                        std::ostringstream a, b;
+                        json_ml(a, m);
+                        json_ml(b, V.get(h, r));
+                        if (a.str() != b.str()) mismatch++;
+                    }
+                os << "],\"onHap\":[";
+                for (size_t r = 0; r < V.numReads(); r++) {
+                    os << (r ? "," : "") << V.onHap(r);
+                    if (V.onHap(r) != onHap[size_t(w)][r]) mismatch++;
+                }
+                os << "]";
+            }
+            os << "}";
+        }
+        os << "],\"mismatch\":" << mismatch << "}";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// bench.py's end-to-end leg: W synthetic windows of the BASELINE shape (H haplotypes of ~HL bp = a random reference plus 1-3-bp
+// indel variants, R reads of L bp sampled from them with 0.1 % substitutions, Q30, mapping quality Phred 40) as the
+// reference's own objects (vector<Haplotype>, vector<Read>), through LikelihoodEngine::computeLikelihoodsBatch.
+// mode: bit0 = eager records (every MLAlignment rebuilt), bit1 = without alignments (lazy only), bit2 = --faster model.
+// out[0..5] = best wall seconds of `reps` calls after one warm-up call, its pack / device / finish split, the ll of window 0
+// pair (0,0), the number of windows with an error.
+int ddh_bench_batch(int W, int H, int R, int L, int HL, unsigned long long seed, int mode, int device, int reps, double *out)
+{
+    try {
+        uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+        auto rnd = [&s]() -> uint64_t { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };   // xorshift64
+        const char *acgt = "ACGT";
+        std::vector<std::vector<Haplotype> > haps(static_cast<size_t>(W));
+        std::vector<std::vector<Read> > reads(static_cast<size_t>(W));
+        for (int w = 0; w < W; w++) {
+            std::string ref(size_t(HL), 'A');
+            for (int i = 0; i < HL; i++) ref[size_t(i)] = acgt[rnd() & 3];
+            haps[size_t(w)].push_back(Haplotype(ref));
+            for (int h = 1; h < H; h++) {
+                const size_t pos = size_t(HL / 2 - 10 + int(rnd() % 20)), ln = 1 + size_t(rnd() % 3);
+                haps[size_t(w)].push_back(Haplotype((rnd() & 1) ? ref.substr(0, pos) + ref.substr(pos + ln)
+                                                                : ref.substr(0, pos) + std::string(ln, acgt[rnd() & 3]) + ref.substr(pos)));
+            }
+            reads[size_t(w)].resize(size_t(R));
+            for (int r = 0; r < R; r++) {
+                const std::string &src = haps[size_t(w)][rnd() % uint64_t(H)].seq;
+                const int off = int(rnd() % src.size()) - L / 2;
+                Read &rd = reads[size_t(w)][size_t(r)];
+                rd.seq.seq.resize(size_t(L));
+                for (int i = 0; i < L; i++) {
+                    const int j = off + i;
+                    rd.seq.seq[size_t(i)] = (j >= 0 && j < int(src.size()) && (rnd() % 1000)) ? src[size_t(j)] : acgt[rnd() & 3];
+                }
+                rd.qual.assign(size_t(L), 0.999);
+                rd.mapQual = 0.9999;
+                rd.posStat.first = 1000.0 + off;
+            }
+        }
+        ObservationModelParameters P;
+        P.setCLIDefaultValues();
+        LikelihoodEngine eng(P, device);
+        const bool eager = (mode & 1) != 0, faster = (mode & 4) != 0;
+        if (mode & 2) eng.setKeepAlignments(false);
+        std::vector<std::vector<std::vector<MLAlignment> > > liks(eager ? size_t(W) : 0);
+        std::vector<std::vector<int> > onHap(eager ? size_t(W) : 0);
+        std::vector<WindowJob> jobs(static_cast<size_t>(W));
+        double best = 1e300;
+        for (int rep = 0; rep <= reps; rep++) {
+            for (int w = 0; w < W; w++) {
+                WindowJob &J = jobs[size_t(w)];
+                J.haps = &haps[size_t(w)]; J.reads = &reads[size_t(w)]; J.leftPos = 1000; J.rightPos = 1000 + uint32_t(HL);
+                if (eager) { J.liks = &liks[size_t(w)]; J.onHap = &onHap[size_t(w)]; }
+            }
+            const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            if (faster) eng.computeLikelihoodsFasterBatch(jobs); else eng.computeLikelihoodsBatch(jobs);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0 && dt < best) {
+                best = dt;
+                out[0] = dt; out[1] = eng.lastPackSeconds; out[2] = eng.lastDeviceSeconds; out[3] = eng.lastUnpackSeconds;
+            }
+        }
+        int nerr = 0;
+        for (int w = 0; w < W; w++) nerr += !jobs[size_t(w)].error.empty();
+        out[4] = (W > 0 && jobs[0].error.empty()) ? jobs[0].result.ll(0, 0) : 0.0;
+        out[5] = nerr;
+        return 0;
+    } catch (std::string &e) {
+        fprintf(stderr, "ddh_bench_batch: %s\n", e.c_str());
+        return -1;
     }
 }
 

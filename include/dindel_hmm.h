@@ -206,6 +206,11 @@ int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, 
 /* The host-pointer entry points keep a device arena, a pinned staging mirror and two streams per host thread between
  * calls (one window per call would otherwise be all allocation overhead); this frees them. */
 void dd_release_cache(void);
+/* Page-locked host memory for the arrays of dd_batch / dd_result: with it the H2D / D2H copies of dd_compute_likelihoods run
+ * at full link speed and truly overlap the kernels (pageable memory is staged by the runtime).  Optional: any host pointer
+ * works.  dd_host_alloc returns NULL when there is no device or the allocation fails. */
+void *dd_host_alloc(size_t bytes);
+void dd_host_free(void *p);
 
 /* ---- (2) device-pointer entry points ------------------------------------------------------ */
 /* Table block built on the host with libm (emission logs per quality, bMid priors per mapping

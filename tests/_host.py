@@ -8,21 +8,9 @@ import numpy as np
 
 from dindel_tgi_amd import capi
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_DIR = os.path.join(ROOT, "dindel_tgi_amd", "host")
-LIB = os.environ.get("DD_HOST_LIB") or os.path.join(HOST_DIR, "libdindel_host.so")
-_lib = None
+from dindel_tgi_amd import hostlib
 
-
-def load():
-    global _lib
-    if _lib is None:
-        capi.load()                     # libdindel_hmm.so (and torch's HIP runtime) first
-        srcs = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith((".cpp", ".hpp"))]
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
-            subprocess.check_call(["make", "-s", "-C", HOST_DIR])
-        _lib = C.CDLL(LIB)
-    return _lib
+load = hostlib.load
 
 
 def _params(p):
@@ -101,3 +89,30 @@ def compute_window_mates(haps, reads, quals, mapq, pos_first, unmapped, left_pos
                                           ls.ctypes.data_as(capi.c_i32p), len(lib_counts), out, len(out))
     assert n > 0, n
     return json.loads(out.value.decode())
+
+
+def batch(windows, params, faster=False, keep_alignments=True, device=0):
+    """LikelihoodEngine::computeLikelihoodsBatch over dindel_tgi_amd.batch.Window objects, eager and lazy (ddh_batch_json):
+    {"windows": [{"error": str, "ll": [...], "onHap": [...]}], "mismatch": lazy-vs-eager differences}."""
+    lib = load()
+    haps = [h for w in windows for h in w.haps]
+    reads = [r for w in windows for r in w.reads]
+    nh = np.asarray([len(w.haps) for w in windows], np.int32)
+    nr = np.asarray([len(w.reads) for w in windows], np.int32)
+    q = np.ascontiguousarray(np.concatenate([np.asarray(r.qual, np.float64).reshape(-1) for r in reads] + [np.zeros(1)]))
+    mq = np.asarray([r.mapQual for r in reads] + [0.0], np.float64)
+    pf = np.asarray([float(r.start) for r in reads] + [0.0], np.float64)
+    um = np.asarray([int(r.unmapped) for r in reads] + [0], np.int32)
+    lp = np.asarray([w.hap_start & 0xFFFFFFFF for w in windows], np.uint32)
+    pd, pi = _params(params)
+    out = C.create_string_buffer(1 << 26)
+    n = lib.ddh_batch_json(len(windows), nh.ctypes.data_as(capi.c_i32p), nr.ctypes.data_as(capi.c_i32p),
+                           "\n".join(haps).encode(), "\n".join(r.seq for r in reads).encode(), q.ctypes.data_as(capi.c_f64p),
+                           mq.ctypes.data_as(capi.c_f64p), pf.ctypes.data_as(capi.c_f64p), um.ctypes.data_as(capi.c_i32p),
+                           lp.ctypes.data_as(capi.c_u32p), pd, pi, (1 if faster else 0) | (0 if keep_alignments else 2), device,
+                           out, len(out))
+    assert n > 0, n
+    return json.loads(out.value.decode())
+
+
+from dindel_tgi_amd.hostlib import bench_batch  # noqa: E402,F401

@@ -250,3 +250,55 @@ def test_engine_random_windows_both_models(seed):
         if any(len(r.seq) < 4 for r in w.reads):
             assert resf == {"throw": "HapHash string too short"}, (str(resf)[:300], [len(r.seq) for r in w.reads], [len(h) for h in w.haps])
     assert n_pairs > 15 and n_whole_ins > 0
+
+
+@pytest.mark.parametrize("faster", [False, True])
+@pytest.mark.parametrize("keep", [True, False])
+def test_batch_lazy_views_equal_eager_records_and_oracle(faster, keep):
+    """computeLikelihoodsBatch over many windows at once: the lazy WindowLikelihoods view (scalars straight from the result
+    block, full records from get() — recomputed per window when the batch kept no alignments) equals the eager
+    MLAlignment records pair by pair, the log-likelihoods equal the oracle's, and a window that cannot be processed (767-bp
+    haplotype; too short a haplotype; a 3-bp read for the --faster model) fails alone with the reference's string."""
+    from tests.test_gpu_fuzz import make_windows
+    rng = np.random.default_rng(99)
+    p = capi.params_cli_defaults()
+    ws = make_windows(rng, 14, 90, 70, min_hap=p.maxLengthDel)
+    if faster:
+        ws = [w for w in ws if all(len(r.seq) >= 4 for r in w.reads)]
+    q = [0.999]
+    hapL = "".join(rng.choice(list("ACGT"), 767))
+    ws.insert(3, Window(1000, [hapL], [ReadRec(hapL[:50], q * 50, 0.9999, 1000)]))                     # outside the kernel limits
+    ws.insert(7, Window(1000, ["ACG", "ACGTACGTAC"], [ReadRec("ACGTA", q * 5, 0.9999, 1000)]))         # hapSize error.
+    if faster:
+        ws.insert(9, Window(1000, ["ACGTACGTACGTA"], [ReadRec("ACG", q * 3, 0.9999, 1000)]))           # HapHash string too short
+    res = _host.batch(ws, p, faster=faster, keep_alignments=keep)
+    assert res["mismatch"] == 0
+    errs = [w["error"] for w in res["windows"]]
+    assert errs[3].startswith("window outside the GPU kernel limits") and errs[7] == "hapSize error."
+    if faster:
+        assert errs[9] == "HapHash string too short"
+    assert sum(1 for e in errs if e) == (3 if faster else 2)
+    n = 0
+    for w, rw in zip(ws, res["windows"]):
+        if rw["error"]:
+            continue
+        i = 0
+        for hap in w.haps:
+            for rd in w.reads:
+                if faster:
+                    o, _ = _oracle.pair_fast(hap, rd.seq, rd.qual, rd.mapQual, rd.start, w.hap_start, p)
+                else:
+                    o, _ = _oracle.pair(hap, rd.seq, rd.qual, rd.mapQual, rd.start, w.hap_start, p, unmapped=rd.unmapped)
+                assert rw["ll"][i] == o.ll, (hap, rd.seq)
+                i += 1
+                n += 1
+    assert n >= 60
+
+
+def test_engine_bench_hook_runs():
+    """The end-to-end leg bench.py reports (ddh_bench_batch): lazy, lazy without alignments and eager agree on ll[0][0][0]."""
+    a = _host.bench_batch(48, reps=1)
+    b = _host.bench_batch(48, reps=1, keep_alignments=False)
+    c = _host.bench_batch(48, reps=1, eager=True)
+    assert a["errors"] == b["errors"] == c["errors"] == 0
+    assert a["ll00"] == b["ll00"] == c["ll00"] and a["ll00"] < 0
