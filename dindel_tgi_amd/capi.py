@@ -112,7 +112,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets", "dd_screen_windows",
-           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_launch_device_faster", "dd_release_cache", "dd_host_alloc", "dd_host_free", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_compute_likelihoods_multi", "dd_compute_likelihoods_faster_multi", "dd_partition_windows", "dd_launch_device_faster", "dd_release_cache", "dd_host_alloc", "dd_host_free", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
@@ -143,6 +143,9 @@ def load():
     lib.dd_batch_offsets.argtypes = [C.POINTER(dd_batch), c_i64p, c_i64p, c_i64p]
     lib.dd_compute_likelihoods.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
     lib.dd_compute_likelihoods_faster.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), C.c_int]
+    lib.dd_compute_likelihoods_multi.argtypes = [C.POINTER(dd_params), C.POINTER(dd_batch), C.POINTER(dd_result), c_i32p, C.c_int]
+    lib.dd_compute_likelihoods_faster_multi.argtypes = lib.dd_compute_likelihoods_multi.argtypes
+    lib.dd_partition_windows.argtypes = [C.POINTER(dd_batch), C.c_int, c_i32p]
     lib.dd_launch_device_faster.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch), C.POINTER(dd_device_result), C.c_void_p]
     lib.dd_release_cache.restype = None
     lib.dd_host_alloc.argtypes = [C.c_size_t]

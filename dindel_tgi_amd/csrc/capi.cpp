@@ -8,6 +8,11 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1312,6 +1317,172 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         g_err = msg;
     }
     return rc;
+}
+
+// ---------------- several devices of one process ----------------
+int dd_partition_windows(const dd_batch *b, int n_parts, int32_t *bounds)
+{
+    if (!b || !bounds || n_parts < 1) return fail(DD_ERR_INVALID, "null argument");
+    if (b->n_windows < 0 || !b->win_hap_off || !b->win_read_off || !b->hap_seq_off || !b->read_seq_off)
+        return fail(DD_ERR_INVALID, "null offset array");
+    const int W = b->n_windows;
+    std::vector<double> cum((size_t)W + 1, 0.0);          // cells before window w (exact in a double far beyond any batch)
+    for (int w = 0; w < W; w++) {
+        const int64_t SH = (int64_t)b->hap_seq_off[b->win_hap_off[w + 1]] - b->hap_seq_off[b->win_hap_off[w]];
+        const int64_t SL = (int64_t)b->read_seq_off[b->win_read_off[w + 1]] - b->read_seq_off[b->win_read_off[w]];
+        cum[(size_t)w + 1] = cum[(size_t)w] + (double)SH * (double)SL;
+    }
+    bounds[0] = 0;
+    for (int i = 1; i < n_parts; i++) {
+        // first boundary whose prefix reaches i/n of the work, moved one window back when that lands closer
+        const double target = cum[(size_t)W] * (double)i / (double)n_parts;
+        int w = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        if (w > 0 && target - cum[(size_t)w - 1] < cum[(size_t)w] - target) w--;
+        if (w < bounds[i - 1]) w = bounds[i - 1];
+        if (w > W) w = W;
+        bounds[i] = w;
+    }
+    bounds[n_parts] = W;
+    return DD_SUCCESS;
+}
+
+namespace {
+
+// One persistent host thread per block slot: its thread_local device cache (arena, pinned mirror, streams) survives between
+// calls, which per-call threads would allocate and free every time.  The threads wait for work for the life of the process.
+class SlotWorker {
+public:
+    SlotWorker() : has_job_(false), done_(true) { th_ = std::thread([this]() { loop(); }); th_.detach(); }
+    void submit(std::function<void()> f)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        job_ = std::move(f); has_job_ = true; done_ = false;
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this]() { return done_; });
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this]() { return has_job_; });
+                f = std::move(job_); has_job_ = false;
+            }
+            f();
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                done_ = true;
+                cv_.notify_all();
+            }
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool has_job_, done_;
+};
+
+std::mutex g_multi_mutex;                       // one multi-device call at a time per process (the slots are shared)
+std::vector<SlotWorker *> g_slots;              // never destroyed: the threads outlive static destruction
+
+int compute_multi(Model model, const dd_params *p, const dd_batch *b, dd_result *r, const int *devices, int n)
+{
+    if (!devices || n < 1) return fail(DD_ERR_INVALID, "dd_compute_likelihoods_multi: no devices");
+    if (n == 1) return compute_likelihoods_impl(model, p, b, r, devices[0]);
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
+    dd_sizes sz;
+    if ((rc = dd_batch_sizes(b, &sz))) return rc;
+    if (sz.n_pairs == 0) return DD_SUCCESS;
+    const int W = b->n_windows;
+    std::vector<int32_t> bounds((size_t)n + 1);
+    if ((rc = dd_partition_windows(b, n, bounds.data()))) return rc;
+    std::vector<int64_t> pair_off((size_t)W + 1), hpos_off((size_t)W + 1), vc_off((size_t)W + 1);
+    dd_batch_offsets(b, pair_off.data(), hpos_off.data(), vc_off.data());
+
+    struct Block {
+        std::vector<int32_t> win_hap_off, win_read_off, hap_seq_off, read_seq_off, hap_var_off;
+        dd_batch b; dd_result r; int rc; std::string err;
+    };
+    std::vector<std::unique_ptr<Block> > blocks;
+    for (int i = 0; i < n; i++) {
+        const int w0 = bounds[(size_t)i], w1 = bounds[(size_t)i + 1];
+        std::unique_ptr<Block> B(new Block());
+        B->rc = DD_SUCCESS;
+        const int h0 = b->win_hap_off[w0], h1 = b->win_hap_off[w1], q0 = b->win_read_off[w0], q1 = b->win_read_off[w1];
+        const int hs0 = b->hap_seq_off[h0], rs0 = b->read_seq_off[q0];
+        const int v0 = b->hap_var_off ? b->hap_var_off[h0] : 0;
+        // offset arrays rebased to the block; data arrays are the caller's, shifted
+        for (int w = w0; w <= w1; w++) { B->win_hap_off.push_back(b->win_hap_off[w] - h0); B->win_read_off.push_back(b->win_read_off[w] - q0); }
+        for (int h = h0; h <= h1; h++) {
+            B->hap_seq_off.push_back(b->hap_seq_off[h] - hs0);
+            if (b->hap_var_off) B->hap_var_off.push_back(b->hap_var_off[h] - v0);
+        }
+        for (int q = q0; q <= q1; q++) B->read_seq_off.push_back(b->read_seq_off[q] - rs0);
+        dd_batch &s = B->b;
+        s = *b;
+        s.n_windows = w1 - w0;
+        s.win_hap_off = B->win_hap_off.data(); s.win_read_off = B->win_read_off.data();
+        s.win_hap_start = b->win_hap_start ? b->win_hap_start + w0 : nullptr;
+        s.hap_seq_off = B->hap_seq_off.data(); s.hap_seq = b->hap_seq ? b->hap_seq + hs0 : nullptr;
+        s.hap_var_off = b->hap_var_off ? B->hap_var_off.data() : nullptr;
+        s.hap_var = b->hap_var ? b->hap_var + 2 * (size_t)v0 : nullptr;
+        s.hap_var_flank = b->hap_var_flank ? b->hap_var_flank + 3 * (size_t)v0 : nullptr;
+        s.read_seq_off = B->read_seq_off.data();
+        s.read_seq = b->read_seq ? b->read_seq + rs0 : nullptr;
+        s.read_qidx = b->read_qidx ? b->read_qidx + rs0 : nullptr;
+        s.read_mqidx = b->read_mqidx ? b->read_mqidx + q0 : nullptr;
+        s.read_start = b->read_start ? b->read_start + q0 : nullptr;
+        s.read_flags = b->read_flags ? b->read_flags + q0 : nullptr;
+        s.read_mate_pos = b->read_mate_pos ? b->read_mate_pos + q0 : nullptr;
+        s.read_mate_len = b->read_mate_len ? b->read_mate_len + q0 : nullptr;
+        s.read_lib = b->read_lib ? b->read_lib + q0 : nullptr;
+        dd_result &o = B->r;
+        memset(&o, 0, sizeof(o));
+        const int64_t p0 = pair_off[(size_t)w0];
+#define SHIFT(f, off) o.f = r->f ? r->f + (off) : nullptr
+        SHIFT(ll, p0); SHIFT(llOn, p0); SHIFT(llOff, p0); SHIFT(mLogBQ, p0); SHIFT(offHap, p0); SHIFT(offHapHMQ, p0);
+        SHIFT(numIndels, p0); SHIFT(numMismatch, p0); SHIFT(nBQT, p0); SHIFT(nmmBQT, p0); SHIFT(nMMLeft, p0); SHIFT(nMMRight, p0);
+        SHIFT(firstBase, p0); SHIFT(lastBase, p0); SHIFT(status, p0);
+        SHIFT(hpos, hpos_off[(size_t)w0]); SHIFT(var_covered, vc_off[(size_t)w0]); SHIFT(var_fcov, vc_off[(size_t)w0]); SHIFT(onHap, q0);
+#undef SHIFT
+        blocks.push_back(std::move(B));
+    }
+    std::lock_guard<std::mutex> g(g_multi_mutex);
+    while ((int)g_slots.size() < n) g_slots.push_back(new SlotWorker());
+    for (int i = 0; i < n; i++) {
+        Block *B = blocks[(size_t)i].get();
+        const int dev = devices[i];
+        g_slots[(size_t)i]->submit([B, model, p, dev]() {
+            B->rc = compute_likelihoods_impl(model, p, &B->b, &B->r, dev);
+            if (B->rc != DD_SUCCESS) B->err = g_err;          // the worker thread's message
+        });
+    }
+    for (int i = 0; i < n; i++) g_slots[(size_t)i]->wait();
+    for (int i = 0; i < n; i++)
+        if (blocks[(size_t)i]->rc != DD_SUCCESS)
+            return fail(blocks[(size_t)i]->rc, "block " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + blocks[(size_t)i]->err);
+    return DD_SUCCESS;
+}
+
+} // namespace
+
+int dd_compute_likelihoods_multi(const dd_params *p, const dd_batch *b, dd_result *r, const int *devices, int n_devices)
+{
+    return compute_multi(MODEL_FBMAXERR, p, b, r, devices, n_devices);
+}
+
+int dd_compute_likelihoods_faster_multi(const dd_params *p, const dd_batch *b, dd_result *r, const int *devices, int n_devices)
+{
+    return compute_multi(MODEL_S, p, b, r, devices, n_devices);
 }
 
 } // extern "C"

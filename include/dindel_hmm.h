@@ -203,6 +203,15 @@ int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos
 /* device >= 0: HIP device ordinal.  Synchronous.  Replaces the body of computeLikelihoods for a
  * batch of windows. */
 int dd_compute_likelihoods(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+/* Several devices of ONE process (the reference is one process, DInDel.cpp:4074): the batch is cut into n_devices contiguous
+ * window blocks balanced by cells (sum over a window's pairs of L * Hs) — dd_partition_windows — and block i
+ * runs on devices[i] under its own host thread, device arena and streams; every block writes straight into the caller's
+ * arrays at its windows' offsets, so the result is the single-device result bit for bit and no collective is needed.
+ * A device may be named more than once (its blocks then run concurrently on it).  Returns the first non-zero code of a block. */
+int dd_compute_likelihoods_multi(const dd_params *p, const dd_batch *b, dd_result *r, const int *devices, int n_devices);
+/* bounds[n_parts+1]: block i = windows [bounds[i], bounds[i+1]) */
+int dd_partition_windows(const dd_batch *b, int n_parts, int32_t *bounds);
+
 /* The host-pointer entry points keep a device arena, a pinned staging mirror and two streams per host thread between
  * calls (one window per call would otherwise be all allocation overhead); this frees them. */
 void dd_release_cache(void);
@@ -292,6 +301,7 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
  * capMapQualFast, maxMismatch.  status: DD_PAIR_HAPSIZE (`throw string("hapSize error.")`, Faster.cpp:47) or
  * DD_PAIR_NAN for a read shorter than the 4-mer (`throw string("HapHash string too short")`, Haplotype.hpp:341). */
 int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_result *r, int device);
+int dd_compute_likelihoods_faster_multi(const dd_params *p, const dd_batch *b, dd_result *r, const int *devices, int n_devices);
 int dd_launch_device_faster(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *stream);
 
 /* ---- N1 (next row): read sums of the diploid genotype reduction --------------------------- */

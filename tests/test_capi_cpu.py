@@ -249,3 +249,31 @@ def test_screen_windows_flags_only_the_offending_windows(lib):
     pb2 = pack([limit, good])
     assert lib.dd_screen_windows(C.byref(pb2.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 0
     assert list(mx) == [766, 1024]
+
+
+def test_partition_windows_balances_cells(lib):
+    """dd_partition_windows (the split dd_compute_likelihoods_multi uses): contiguous, covering, and balanced by
+    sum(H*R*L*Hs) — not by window count — on windows of very different weight."""
+    rng = np.random.default_rng(10)
+    ws = []
+    for i in range(40):
+        hl = int(rng.integers(20, 200)); nr = int(rng.integers(0, 12)) * (8 if i % 7 == 0 else 1)
+        hap = "".join(rng.choice(list("ACGT"), hl))
+        ws.append(Window(1000, [hap] * int(rng.integers(1, 4)), [ReadRec(hap[:30].ljust(30, "A"), [0.99] * 30, 0.99, 1000)] * nr))
+    pb = pack(ws)
+    b = pb.ctypes_batch()
+    hl = np.diff(pb.a["hap_seq_off"]).astype(np.int64); rl = np.diff(pb.a["read_seq_off"]).astype(np.int64)
+    cells = np.array([hl[pb.a["win_hap_off"][w]:pb.a["win_hap_off"][w + 1]].sum() * rl[pb.a["win_read_off"][w]:pb.a["win_read_off"][w + 1]].sum()
+                      for w in range(pb.n_windows)], np.float64)
+    assert cells.sum() == pb.cells
+    for n in (1, 2, 3, 8, 64):
+        bounds = np.zeros(n + 1, np.int32)
+        assert lib.dd_partition_windows(C.byref(b), n, bounds.ctypes.data_as(capi.c_i32p)) == 0
+        assert bounds[0] == 0 and bounds[-1] == pb.n_windows and (np.diff(bounds) >= 0).all()
+        if n <= 8:
+            per = np.array([cells[bounds[i]:bounds[i + 1]].sum() for i in range(n)])
+            assert per.max() <= cells.sum() / n + cells.max()          # no block exceeds its share by more than one window
+    empty = pack([Window(1000, ["ACGT"], [])] * 3)
+    bounds = np.zeros(3, np.int32)
+    assert lib.dd_partition_windows(C.byref(empty.ctypes_batch()), 2, bounds.ctypes.data_as(capi.c_i32p)) == 0
+    assert bounds[0] == 0 and bounds[2] == 3

@@ -402,3 +402,36 @@ def test_unsupported_window_fails_alone(lib, faster):
     arrs, res = alloc_result(pb2, fill=None)
     assert fn(C.byref(p), C.byref(pb2.ctypes_batch()), C.byref(res), 0) == 0, capi.last_error()
     assert (arrs["status"][:pb2.n_pairs] == capi.DD_PAIR_UNSUPPORTED).all() and not arrs["onHap"][:pb2.n_reads].any()
+
+
+@pytest.mark.parametrize("faster", [False, True])
+def test_multi_device_entry_equals_single_call(lib, faster):
+    """dd_compute_likelihoods_multi with devices = {0, 0} / {0, 0, 0} (two / three window blocks, each under its own host
+    thread, arena and streams, concurrently on the one GPU of this box) writes exactly the single call's arrays."""
+    from tests.test_gpu_fuzz import make_windows
+    rng = np.random.default_rng(606)
+    p = capi.params_cli_defaults()
+    ws = make_windows(rng, 90, 160, 120, min_hap=max(p.maxLengthDel, 4), with_vars=True)
+    if faster:
+        ws = [Window(w.hap_start, w.haps, [r for r in w.reads if len(r.seq) >= 4], hap_vars=w.hap_vars, hap_var_flanks=w.hap_var_flanks) for w in ws]
+    pb = pack(ws)
+    b = pb.ctypes_batch()
+    one, res1 = alloc_result(pb, fill=None)
+    fn1 = lib.dd_compute_likelihoods_faster if faster else lib.dd_compute_likelihoods
+    fnm = lib.dd_compute_likelihoods_faster_multi if faster else lib.dd_compute_likelihoods_multi
+    assert fn1(C.byref(p), C.byref(b), C.byref(res1), 0) == 0, capi.last_error()
+    for devs in ([0, 0], [0, 0, 0]):
+        many, resm = alloc_result(pb, fill=None)
+        d = np.asarray(devs, np.int32)
+        for _rep in range(2):                      # the second call reuses the workers' cached arenas
+            assert fnm(C.byref(p), C.byref(b), C.byref(resm), d.ctypes.data_as(capi.c_i32p), len(devs)) == 0, capi.last_error()
+        n = {"hpos": pb.hpos_len, "var_covered": pb.var_cov_len, "var_fcov": pb.var_cov_len, "onHap": pb.n_reads}
+        ok = one["status"][:pb.n_pairs] == 0
+        for k in one:
+            if k == "hpos" and not ok.all():
+                continue                           # hpos of a failed pair is not written by either call
+            m = n.get(k, pb.n_pairs)
+            assert np.array_equal(one[k][:m], many[k][:m]), (devs, k)
+    bad = np.asarray([0, 99], np.int32)
+    assert fnm(C.byref(p), C.byref(b), C.byref(resm), bad.ctypes.data_as(capi.c_i32p), 2) == capi.DD_ERR_NO_DEVICE
+    assert "block 1" in capi.last_error()
