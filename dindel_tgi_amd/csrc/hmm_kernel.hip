@@ -36,16 +36,24 @@ namespace ddk {
 // Diagnostic build only (-DDD_STAMPS): per-phase s_memtime shares, summed into P.dbg[phase].  Never
 // compiled into the product library; the stamps go to a buffer of their own and feed no output.
 #ifdef DD_STAMPS
+// One s_memtime per stamp, accumulated per wave in registers and flushed with one atomic per phase when the wave retires
+// (an atomic per stamp cost more than the phases it was timing).
 #define STAMP(i)                                                                  \
     do {                                                                          \
-        unsigned long long _t = __builtin_amdgcn_s_memtime();                     \
-        if (lane == 0 && P.dbg) atomicAdd(&P.dbg[i], _t - _tprev);                \
-        _tprev = __builtin_amdgcn_s_memtime();                                    \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();               \
+        _acc[i] += _t - _tprev;                                                   \
+        _tprev = _t;                                                              \
     } while (0)
-#define STAMP_INIT unsigned long long _tprev = __builtin_amdgcn_s_memtime()
+#define STAMP_INIT unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tprev = __builtin_amdgcn_s_memtime()
+#define STAMP_FLUSH                                                               \
+    do {                                                                          \
+        if (lane == 0 && P.dbg)                                                   \
+            for (int _i = 0; _i < 8; _i++) atomicAdd(&P.dbg[_i], _acc[_i]);       \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMP_INIT do { } while (0)
+#define STAMP_FLUSH do { } while (0)
 #endif
 #define NEG_INF (-__builtin_huge_val())
 
@@ -707,71 +715,92 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         {
-            // the chain is wave-uniform: keep it on the scalar unit (readfirstlane) so the ~L dependent steps
-            // cost no VALU issue slots beyond the LDS address move and the recorded state
-            int sL = __builtin_amdgcn_readfirstlane(mapHMQ), sR = sL;
-            if (lane == 0) ms[bMid] = (int16_t)sL;
-            const int nL = bMid, nR = L - 1 - bMid;
-            const int n = nL > nR ? nL : nR;
-            const unsigned chmask = (1u << BP::CB) - 1u, insbit = 1u << BP::CB;
-            // Whole back-pointer rows are fetched TB rows ahead for both chains (their addresses do not depend on
-            // the chain: lane l reads word l of the row), so the dependent part of each step is a v_readlane, not a
-            // memory round trip — one LDS / L2 latency per TB steps instead of per step.
-            constexpr int TB = 8;
-            for (int i0 = 0; i0 < n; i0 += TB) {
-                btword_t rowL[TB], rowR[TB];
-#pragma unroll
-                for (int j = 0; j < TB; j++) {
-                    rowL[j] = (i0 + j < nL) ? bt[(bMid - (i0 + j)) * 64 + lane] : (btword_t)0;
-                    rowR[j] = (i0 + j < nR) ? bt[(bMid + (i0 + j) + 1) * 64 + lane] : (btword_t)0;
+            // A MAP path is mostly RUNS: the read walks down a diagonal of the haplotype (every step "from the base before",
+            // ch == 1), or sits left / right of it (LO, RO: "stay").  A run is recognised 64 rows at a time: lane j fetches
+            // the back-pointer field the path would use j steps ahead IF the run continued (row b -/+ j, position x -/+ j),
+            // a ballot gives the run length, and the 64 states are stored lane-parallel.  Only the events between runs (an
+            // indel, entering or leaving the haplotype) take the scalar, one-row-at-a-time decode — a typical read needs 2-4
+            // of those instead of ~L dependent steps (the serial walk was 19 % of the kernel's wave time).
+            constexpr unsigned chmask = (1u << BP::CB) - 1u, fmask = (1u << BP::PB) - 1u;
+            auto fieldAt = [&](int row, int x) -> unsigned {               // per-lane row / position: the PB bits of that state
+                const int src = x / K, sh = (x - src * K) * BP::PB;
+                return (unsigned)(bt[row * 64 + src] >> sh) & fmask;
+            };
+            const int s0 = __builtin_amdgcn_readfirstlane(mapHMQ);
+            if (lane == 0) ms[bMid] = (int16_t)s0;
+            // ---- towards base 0: mapState[b-1] = btf[b][mapState[b]] ----
+            {
+                int ins = s0 >= numS ? 1 : 0, x = s0 - (ins ? numS : 0), b = bMid;
+                while (b > 0) {
+                    unsigned f;
+                    if (!ins && x == 0) {                                  // LO is absorbing in this direction (:1798-1799)
+                        for (int j = lane; j < b; j += 64) ms[j] = 0;
+                        break;
+                    }
+                    if (!ins && x != RO) {                                 // diagonal run: rows b, b-1, ...; positions x, x-1, ...
+                        const int maxrun = b < 64 ? b : 64;
+                        const bool valid = lane < maxrun && x - lane >= 1;
+                        f = valid ? fieldAt(b - lane, x - lane) : 0u;
+                        const unsigned long long m = __ballot(valid && (f & chmask) == 1u);
+                        const int run = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+                        if (lane < run) ms[b - 1 - lane] = (int16_t)(x - 1 - lane);
+                        b -= run; x -= run;
+                        if (b == 0) break;
+                        if (run == maxrun || x == 0) continue;             // next 64 rows / reached LO
+                        f = (unsigned)__builtin_amdgcn_readlane((int)f, run);   // the row that ended the run: decode it below
+                    } else {
+                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b, x));
+                    }
+                    // one row, any state.  on base x: ch = jump length y (from x-y), 0 = from the inserted state numS+x-1;
+                    // RO: 0 RO, 1 Hs, 2 numS+RO, 3 numS+Hs.  inserted at x: bit set = entered from "on base x", else stays
+                    const int ch = (int)(f & chmask), ib = (int)(f >> BP::CB);
+                    const int z = ch == 0 ? 1 : 0;
+                    int gx = x - ch - z, gi = z;
+                    if (x == RO) { gx = RO - (ch & 1); gi = ch >> 1; }
+                    if (ins) { gx = x; gi = ib ^ 1; }
+                    x = gx; ins = gi;
+                    if (lane == 0) ms[b - 1] = (int16_t)(ins ? numS + x : x);
+                    b--;
                 }
-#pragma unroll
-                for (int j = 0; j < TB; j++) {
-                    const int i = i0 + j;
-                    if (i < nL) {                             // mapState[b-1] = btf[b][mapState[b]]
-                        const int b = bMid - i;
-                        const bool ins = sL >= numS;
-                        const int x = ins ? sL - numS : sL;
-                        const int src = x / K;
-                        unsigned byte;
-                        if (sizeof(btword_t) == 8) {
-                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowL[j] & 0xffffffffu), src);
-                            const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowL[j] >> 32), src);
-                            byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
-                        } else {
-                            byte = (unsigned)__builtin_amdgcn_readlane((unsigned)rowL[j], src) >> ((x % K) * BP::PB);
-                        }
-                        const unsigned ch = byte & chmask;
-                        int p;
-                        if (ins) p = (byte & insbit) ? x : sL;
-                        else if (x == 0) p = 0;
-                        else if (x == RO) p = (ch == 0) ? RO : (ch == 1) ? Hs : (ch == 2) ? numS + RO : numS + Hs;
-                        else p = (ch == 0) ? numS + x - 1 : x - (int)ch;
-                        sL = p;
-                        if (lane == 0) ms[b - 1] = (int16_t)p;
+            }
+            // ---- towards base L-1: mapState[b+1] = btb[b][mapState[b]], stored at row b+1 ----
+            {
+                int ins = s0 >= numS ? 1 : 0, x = s0 - (ins ? numS : 0), b = bMid;
+                while (b < L - 1) {
+                    unsigned f;
+                    if (!ins) {
+                        const int left = L - 1 - b, maxrun = left < 64 ? left : 64;
+                        const bool stay = (x == 0 || x == RO);             // LO / RO: code 0 = stays
+                        const bool valid = lane < maxrun && (stay || x + lane <= Hs);
+                        f = valid ? fieldAt(b + 1 + lane, stay ? x : x + lane) : 0u;
+                        const unsigned long long m = __ballot(valid && (f & chmask) == (stay ? 0u : 1u));
+                        const int run = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+                        if (lane < run) ms[b + 1 + lane] = (int16_t)(stay ? x : x + 1 + lane);
+                        b += run;
+                        if (!stay) x += run;
+                        if (b >= L - 1) break;
+                        if (run == maxrun) continue;
+                        if (!stay && x > Hs) continue;                     // the diagonal ran into RO: next round handles it as a stay run
+                        f = (unsigned)__builtin_amdgcn_readlane((int)f, run);
+                    } else {
+                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b + 1, x));
                     }
-                    if (i < nR) {                             // mapState[b+1] = btb[b][mapState[b]] (stored at row b+1)
-                        const int b = bMid + i;
-                        const bool ins = sR >= numS;
-                        const int x = ins ? sR - numS : sR;
-                        const int src = x / K;
-                        unsigned byte;
-                        if (sizeof(btword_t) == 8) {
-                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowR[j] & 0xffffffffu), src);
-                            const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)rowR[j] >> 32), src);
-                            byte = (unsigned)((((uint64_t)hi << 32) | lo) >> ((x % K) * BP::PB));
-                        } else {
-                            byte = (unsigned)__builtin_amdgcn_readlane((unsigned)rowR[j], src) >> ((x % K) * BP::PB);
-                        }
-                        const unsigned ch = byte & chmask;
-                        int p;
-                        if (ins) p = (byte & insbit) ? (x == 0 ? 0 : (x + 1 > RO ? RO : x + 1)) : sR;
-                        else if (x == 0) p = (ch == 0) ? 0 : (ch == 1) ? 1 : numS;
-                        else if (x == RO) p = (ch == 0) ? RO : numS + RO;
-                        else p = (ch == 0) ? numS + x : x + (int)ch;
-                        sR = p;
-                        if (lane == 0) ms[b + 1] = (int16_t)p;
+                    // on base x: ch = jump length y (to x+y), 0 = to the inserted state numS+x; LO: 0 LO, 1 base 1, 2 numS;
+                    // RO: 0 RO, else numS+RO.  inserted at x: bit set = leaves to min(x+1, RO) (LO's stays LO), else stays
+                    const int ch = (int)(f & chmask), ib = (int)(f >> BP::CB);
+                    const int z = ch == 0 ? 1 : 0;
+                    int gx = x + ch, gi = z;
+                    if (x == RO) { gx = RO; gi = z ^ 1; }
+                    if (x == 0) { gx = ch & 1; gi = ch >> 1; }
+                    if (ins) {
+                        int lx = x + 1 > RO ? RO : x + 1;
+                        if (x == 0) lx = 0;
+                        gx = ib ? lx : x;
+                        gi = ib ^ 1;
                     }
+                    x = gx; ins = gi;
+                    if (lane == 0) ms[b + 1] = (int16_t)(ins ? numS + x : x);
+                    b++;
                 }
             }
         }
@@ -828,15 +857,26 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             const unsigned long long bq = __ballot(pBQT);
             nBQT += __popcll(bq);
             // mLogBQ: the reference adds log10(1-q) base by base in read order (:1404-1407); fp64 + is not
-            // associative, so the sum runs serially over the lanes in order (adding +0.0 for skipped bases
-            // is exact).  Cross-lane reads through v_readlane: no LDS round trip per base.
+            // associative, so the sum runs serially in that order (adding +0.0 for skipped bases is exact).  The terms
+            // go through the (now idle) emission staging buffer: every lane reads term i from the same LDS address
+            // (a broadcast), so a term costs one v_add_f64 — no cross-lane moves.
             if (bq) {
-                const int lo = __double2loint(cb), hi = __double2hiint(cb);
-                const int nb = (L - b0) < 64 ? (L - b0) : 64;
-                for (int i = 0; i < nb; i++) {
-                    const int l2 = __builtin_amdgcn_readlane(lo, i), h2 = __builtin_amdgcn_readlane(hi, i);
-                    mLogBQ += __hiloint2double(h2, l2);
+                double *cbuf = rdE;                       // [2 * Lmax] doubles: lane < L - b0 <= Lmax fits
+                if (b < L) cbuf[lane] = cb;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int first = __ffsll((long long)bq) - 1, last = 63 - __clzll((long long)bq);   // +0.0 terms outside change nothing
+                int i = first;
+                for (; i + 8 <= last + 1; i += 8) {
+                    double t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) t[j] = cbuf[i + j];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) mLogBQ += t[j];
                 }
+                for (; i <= last; i++) mLogBQ += cbuf[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
 #pragma unroll
@@ -916,6 +956,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         // order, same wave) the next pair's LDS writes, and DS ops of one wave execute in order.
     }
     }   // item loop
+    STAMP_FLUSH;
 }
 
 // onHap[r] = 1 iff any haplotype of the window has !offHapHMQ for read r (DInDel.cpp:1710, 1720)

@@ -1,0 +1,145 @@
+// valu_rate.hip — issue cost of the VALU instructions the HMM kernels are made of, on gfx950, at 1..4 waves per SIMD.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+//
+// Each test is a loop of 64 independent instructions of one kind (8 register sets round-robin, so no instruction waits on
+// the one before it) run by every wave of a workgroup of 256 x W threads (W waves per SIMD) on every CU; the figure printed
+// is SIMD cycles per wave-instruction = elapsed shader cycles (s_memtime) x 1 / (instructions issued per SIMD), i.e. the
+// reciprocal throughput one SIMD sustains for that instruction.  Prices the instruction-mix table of profiles/r02.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define ITER 2000
+
+template <int OP>
+__global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long long *cyc, double seed)
+{
+    double a[8], b[8];
+    unsigned u[8];
+    float f[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed * (i + 1) + threadIdx.x * 1e-9; b[i] = -seed * (i + 2); u[i] = threadIdx.x + i; f[i] = float(i) + float(seed); }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (OP == 0) {
+#define X(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                REP8(X)
+#undef X
+            } else if (OP == 1) {
+#define X(i) asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                REP8(X)
+#undef X
+            } else if (OP == 2) {
+#define X(i) asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(a[i]), "v"(b[i]) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 3) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 4) & 7]) : );
+                REP8(X)
+#undef X
+            } else if (OP == 4) {
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == 5) {
+#define X(i) asm volatile("v_cmp_gt_u64 vcc, %0, %1" : : "v"(a[i]), "v"(b[i]) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 6) {
+#define X(i) asm volatile("v_mov_b64 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+                REP8(X)
+#undef X
+            } else if (OP == 7) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == 8) {
+#define X(i) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(u[i]), "v"(u[(i + 1) & 7]) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 9) {      // the hysteresis step of the right->middle pass: add, compare, 3 selects
+#define X(i) asm volatile("v_add_f64 %1, %0, %3\n v_cmp_gt_f64 vcc, %2, %1\n v_cndmask_b32 %4, %4, %5, vcc" : "+v"(a[i]), "+v"(b[i]) : "v"(a[(i + 1) & 7]), "v"(seed), "v"(u[i]), "v"(u[(i + 1) & 7]) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 10) {
+#define X(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[i]) : "v"(b[i]));
+                REP8(X)
+#undef X
+            } else if (OP == 11) {
+#define X(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == 12) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                REP8(X)
+#undef X
+            } else if (OP == 13) {
+#define X(i) asm volatile("v_cmp_ge_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a[i]) : "v"(b[i]), "v"(u[i]), "v"(u[(i + 1) & 7]) : "vcc");
+                REP8(X)
+#undef X
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+    for (int i = 0; i < 8; i++) s += a[i] + b[i] + u[i] + f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+#define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); exit(1); } } while (0)
+static double *g_out = nullptr;
+static unsigned long long *g_cyc = nullptr;
+
+template <int OP> static void run(const char *name, int instr_per_x)
+{
+    for (int w = 1; w <= 3; w++) {   // the product kernels run 2-3 waves per SIMD (1024-thread workgroups of this loop faulted intermittently on the test box)
+        const int threads = 256 * w, blocks = 256;
+        if (!g_out) {                                  // once, for the largest launch
+            CHECK(hipMalloc(&g_out, sizeof(double) * 1024 * 256));
+            CHECK(hipMalloc(&g_cyc, sizeof(unsigned long long) * 256 * 16));
+        }
+        double *out = g_out;
+        unsigned long long *cyc = g_cyc;
+        hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(blocks * (threads / 64));
+        CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double mean = 0;
+        for (auto v : h) mean += double(v);
+        mean /= double(h.size());
+        // a SIMD runs w waves; each issues ITER*64*instr_per_x wave-instructions in `mean` cycles
+        const double per = mean / (double(ITER) * 64.0 * instr_per_x * w);
+        printf("%-34s waves/SIMD=%d  cycles per wave-instruction on one SIMD: %6.2f   (wave-time per instruction %6.2f)\n", name, w, per,
+               mean / (double(ITER) * 64.0 * instr_per_x));
+        fflush(stdout);
+    }
+}
+
+int main()
+{
+    run<0>("v_add_f64", 1);
+    run<1>("v_max_f64", 1);
+    run<2>("v_cmp_gt_f64", 1);
+    run<3>("v_cndmask_b32", 1);
+    run<4>("v_add_u32", 1);
+    run<5>("v_cmp_gt_u64", 1);
+    run<6>("v_mov_b64", 1);
+    run<7>("v_add_f32", 1);
+    run<8>("v_cmp_gt_u32", 1);
+    run<9>("add_f64+cmp_gt_f64+cndmask (3)", 3);
+    run<10>("v_lshl_add_u64", 1);
+    run<11>("v_min_u32", 1);
+    run<12>("v_pk_add_f32", 1);
+    run<13>("cmp_ge_f64+cndmask (2)", 2);
+    return 0;
+}
