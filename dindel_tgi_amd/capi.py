@@ -102,7 +102,7 @@ class dd_device_batch(C.Structure):
 
 
 class dd_length_classes(C.Structure):
-    _fields_ = [("hap_class_off", C.c_int32 * 8), ("hap_class_max", C.c_int32 * 7), ("n_read_classes", C.c_int32),
+    _fields_ = [("hap_class_off", C.c_int32 * 13), ("hap_class_max", C.c_int32 * 12), ("n_read_classes", C.c_int32),
                 ("read_class_lo", C.c_int32 * 2), ("read_class_max", C.c_int32 * 2)]
 
 

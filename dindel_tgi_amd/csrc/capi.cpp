@@ -48,8 +48,9 @@ double hp_error(int hpLen)
 
 int pick_K(int max_hap_len)
 {
-    static const int ks[] = {1, 2, 3, 4, 6, 8, 12};
-    for (int k : ks)
+    // numS = Hs + 2 states over 64 lanes: every K = 1..12 is instantiated, so no shape pays for positions it does not have
+    // (round 1 had {1,2,3,4,6,8,12}: a 383-bp haplotype ran on 512 positions instead of 448)
+    for (int k = 1; k <= 12; k++)
         if (64 * k >= max_hap_len + 2) return k;
     return -1;
 }
@@ -547,7 +548,7 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
     return T_END;
 }
 
-static const int kHapClassBounds[DD_N_HAP_CLASSES] = {62, 126, 190, 254, 382, 510, DD_MAX_HAP_LEN};   // 64*K - 2
+static const int kHapClassBounds[DD_N_HAP_CLASSES] = {62, 126, 190, 254, 318, 382, 446, 510, 574, 638, 702, DD_MAX_HAP_LEN};   // 64*K - 2
 static const int kReadClassBounds[2] = {160, DD_MAX_READ_LEN};
 
 int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out)

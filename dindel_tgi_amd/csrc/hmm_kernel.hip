@@ -29,6 +29,11 @@
 #include <atomic>
 #include "hmm_kernel.h"
 
+// which pieces this translation unit carries (see the instantiation block at the end of the file)
+#if defined(DD_ONLY_K) || !defined(DD_INST_D) || DD_INST_D == 0 || DD_INST_D == 6
+#define DD_INST_COMMON 1
+#endif
+
 namespace ddk {
 
 #define DD_EPS 1e-10
@@ -959,6 +964,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     STAMP_FLUSH;
 }
 
+#ifdef DD_INST_COMMON
 // onHap[r] = 1 iff any haplotype of the window has !offHapHMQ for read r (DInDel.cpp:1710, 1720)
 __global__ void dd_onhap_kernel(const KernelArgs P)
 {
@@ -983,6 +989,7 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
     }
     P.out.onHap[r] = (uint8_t)on;
 }
+#endif
 
 template <int K, int D, bool GBT>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
@@ -1014,6 +1021,9 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned gri
                : launch_one<DD_ONLY_K, DD_ONLY_D, false>(A, dim3(grid), waves, lds, st);
 }
 #else
+// The product library instantiates K = 1..12 positions per lane x the D builds 6 / 11 / 12 x {LDS, HBM-scratch} back-pointers:
+// 72 kernels.  The file is compiled once per D build (-DDD_INST_D=6|11|12, see the Makefile) so that they build in parallel;
+// the D = 6 unit also carries the dispatcher and the small kernels.
 template <int D, bool GBT>
 static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
@@ -1022,30 +1032,57 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
     case 2: return launch_one<2, D, GBT>(A, grid, waves, lds, st);
     case 3: return launch_one<3, D, GBT>(A, grid, waves, lds, st);
     case 4: return launch_one<4, D, GBT>(A, grid, waves, lds, st);
+    case 5: return launch_one<5, D, GBT>(A, grid, waves, lds, st);
     case 6: return launch_one<6, D, GBT>(A, grid, waves, lds, st);
+    case 7: return launch_one<7, D, GBT>(A, grid, waves, lds, st);
     case 8: return launch_one<8, D, GBT>(A, grid, waves, lds, st);
+    case 9: return launch_one<9, D, GBT>(A, grid, waves, lds, st);
+    case 10: return launch_one<10, D, GBT>(A, grid, waves, lds, st);
+    case 11: return launch_one<11, D, GBT>(A, grid, waves, lds, st);
     case 12: return launch_one<12, D, GBT>(A, grid, waves, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <bool GBT>
-static hipError_t launch_d(int K, int Dt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+#ifndef DD_INST_D
+#define DD_INST_D 0            // 0: every D build in this unit
+#endif
+hipError_t launch_hmm_d6(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d11(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+#if DD_INST_D == 0 || DD_INST_D == 6
+hipError_t launch_hmm_d6(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
-    switch (Dt) {
-    case 6: return launch_k<6, GBT>(K, A, g, waves, lds, st);
-    case 11: return launch_k<11, GBT>(K, A, g, waves, lds, st);
-    case 12: return launch_k<12, GBT>(K, A, g, waves, lds, st);
-    default: return hipErrorInvalidValue;
-    }
+    return gbt ? launch_k<6, true>(K, A, g, waves, lds, st) : launch_k<6, false>(K, A, g, waves, lds, st);
 }
-
-hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+#endif
+#if DD_INST_D == 0 || DD_INST_D == 11
+hipError_t launch_hmm_d11(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
-    return gbt ? launch_d<true>(K, Dt, A, dim3(grid), waves, lds, st) : launch_d<false>(K, Dt, A, dim3(grid), waves, lds, st);
+    return gbt ? launch_k<11, true>(K, A, g, waves, lds, st) : launch_k<11, false>(K, A, g, waves, lds, st);
+}
+#endif
+#if DD_INST_D == 0 || DD_INST_D == 12
+hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+{
+    return gbt ? launch_k<12, true>(K, A, g, waves, lds, st) : launch_k<12, false>(K, A, g, waves, lds, st);
 }
 #endif
 
+#ifdef DD_INST_COMMON
+hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+{
+    switch (Dt) {
+    case 6: return launch_hmm_d6(K, gbt, A, dim3(grid), waves, lds, st);
+    case 11: return launch_hmm_d11(K, gbt, A, dim3(grid), waves, lds, st);
+    case 12: return launch_hmm_d12(K, gbt, A, dim3(grid), waves, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif
+#endif
+
+#ifdef DD_INST_COMMON
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)
 {
     const int n = A.read_end - A.read_begin;
@@ -1053,5 +1090,6 @@ hipError_t launch_onhap(const KernelArgs &A, hipStream_t st)
     hipLaunchKernelGGL(dd_onhap_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
     return hipGetLastError();
 }
+#endif
 
 } // namespace ddk

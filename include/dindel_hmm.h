@@ -248,7 +248,7 @@ int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off
  * non-empty (haplotype class, read class) gets its own launch plan, so one long haplotype or read does not put the whole
  * batch on the slower build.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the
  * summary once on the host (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
-#define DD_N_HAP_CLASSES 7
+#define DD_N_HAP_CLASSES 12
 typedef struct dd_length_classes {
     int32_t hap_class_off[DD_N_HAP_CLASSES + 1];  /* class c owns hap_class_list[hap_class_off[c] .. hap_class_off[c+1])   */
     int32_t hap_class_max[DD_N_HAP_CLASSES];      /* longest haplotype of the class (0 = empty class)                      */

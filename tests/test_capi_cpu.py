@@ -176,7 +176,8 @@ def test_launch_plan_rules(lib):
         assert lib.dd_plan_info(C.byref(p), hap, L, 1, reads, haps, C.byref(out)) == 0, capi.last_error()
         return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7])
     # lane tiling by haplotype length: numS = Hs+2 <= 64 K
-    assert [plan(hap=h)["K"] for h in (62, 63, 126, 127, 190, 191, 254, 255, 382, 383, 510, 511, 766)] == [1, 2, 2, 3, 3, 4, 4, 6, 6, 8, 8, 12, 12]
+    assert [plan(hap=h)["K"] for h in (62, 63, 126, 127, 190, 191, 254, 255, 318, 319, 382, 383, 446, 447, 510, 511, 702, 703, 766)] == \
+        [1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 11, 12, 12]
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 3
@@ -206,10 +207,10 @@ def test_length_classes_and_library_tables_on_the_host(lib):
     lst = np.zeros(pb.n_haps, np.int32)
     assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     hl = np.diff(pb.a["hap_seq_off"])
-    c = np.searchsorted([62, 126, 190, 254, 382, 510, 766], hl, side="left")
-    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=7)).tolist()
+    c = np.searchsorted([64 * k - 2 for k in range(1, 13)], hl, side="left")
+    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=12)).tolist()
     assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    for k in range(7):
+    for k in range(12):
         seg = lst[cls.hap_class_off[k]:cls.hap_class_off[k + 1]]
         assert (c[seg] == k).all() and (np.diff(seg) > 0).all()
         assert cls.hap_class_max[k] == (int(hl[seg].max()) if len(seg) else 0)
@@ -242,8 +243,8 @@ def test_screen_windows_flags_only_the_offending_windows(lib):
     lst = np.zeros(pb.n_haps, np.int32)
     assert lib.dd_build_length_classes(C.byref(b), skip.ctypes.data_as(capi.c_u8p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    assert list(cls.hap_class_max) == [1, 100, 130, 0, 0, 0, 0]          # class 0 holds the skipped haplotypes only
-    assert list(cls.hap_class_off) == [0, 4, 6, 8, 8, 8, 8, 8]
+    assert list(cls.hap_class_max) == [1, 100, 130] + [0] * 9            # class 0 holds the skipped haplotypes only
+    assert list(cls.hap_class_off) == [0, 4, 6] + [8] * 10
     assert cls.n_read_classes == 1 and cls.read_class_max[0] == 80
     assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == capi.DD_ERR_UNSUPPORTED
     pb2 = pack([limit, good])
