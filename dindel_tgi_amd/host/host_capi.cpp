@@ -483,3 +483,48 @@ int ddh_bench_batch(int W, int H, int R, int L, int HL, unsigned long long seed,
 }
 
 } // extern "C"
+
+// ---- N3: the .glf.txt output surface (glf_output.hpp) ----
+#include <fstream>
+#include "glf_output.hpp"
+
+extern "C" {
+
+// how the table prints a double: default ostream formatting (6 significant digits), as OutputData::Line::set does
+int ddh_format_double(double x, char *out, int cap)
+{
+    std::ostringstream os;
+    OutputData od(os);
+    od("v");
+    OutputData::Line line(od);
+    line.set("v", x);
+    return emit(line.get("v"), out, cap);
+}
+
+// Writes a small .glf.txt through the C++ API: header, a skipped-window line for `thrown`, one dip.map line and one per-position
+// "dip" line from the numbers given (vals: qual, msq, genoqual, logZ, mLogBQ sum).  Returns the number of lines written.
+int ddh_glf_demo(const char *path, const char *thrown, const double *vals)
+{
+    try {
+        std::ofstream f(path);
+        OutputData glf = makeGLFOutputData(f);
+        glf.outputLine(glf.headerString());
+        glf.output(skippedWindowLine(glf, skippedMessage(thrown), 7, "20", 1000123u, 1000243u));
+        DipMapCall c;
+        c.index = 8; c.tid = "20"; c.leftPos = 2000000u; c.rightPos = 2000120u; c.candPos = 2000060u; c.realignedPos = 2000058; c.was_candidate = 1;
+        c.qual = vals[0]; c.nref_all = "-AC"; c.num_reads = 173; c.msq = vals[1]; c.numf = 11; c.numr = 9; c.vc_f = 12; c.vc_r = 10;
+        c.numUnmappedRealigned = 2; c.genotype = "0/1"; c.genoqual = vals[2];
+        glf.output(dipMapLine(glf, c));
+        DipPositionRow d;
+        d.index = 8; d.tid = "20"; d.program = "dip"; d.leftPos = 2000000u; d.rightPos = 2000120u; d.candPos = 2000060u; d.realignedPos = 2000058;
+        d.has_variants_in_window = 1; d.logZ = vals[3]; d.nBQT = 15000; d.nmmBQT = 37; d.mLogBQ = vals[4]; d.nMMLeft = 3; d.nMMRight = 1;
+        d.nref_all = "-AC"; d.num_reads = 173; d.msq = vals[1]; d.numOffAll = 4; d.num_indel = 21; d.nf = 11; d.nr = 9;
+        d.var_coverage_forward = "12"; d.var_coverage_reverse = "10"; d.glf = "0/0:-310.5,0/1:-250.25,1/1:-400"; d.numUnmappedRealigned = 2;
+        glf.output(dipPositionLine(glf, d));
+        return glf.lines();
+    } catch (std::string &e) {
+        return -1;
+    }
+}
+
+} // extern "C"
