@@ -74,8 +74,8 @@ __device__ __forceinline__ int builtin_symbol(unsigned ch)
     return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? DD_SYM_N : 31;
 }
 
-// hap[y]=='N' || hap[y]==nuc  (ObservationModelFB.cpp:246); state symbol 4 = 'N' or LO/RO (always eq)
-__device__ __forceinline__ bool code_match(int scode, int rcol) { return scode == DD_SYM_N || scode == rcol; }
+// hap[y]=='N' || hap[y]==nuc  (ObservationModelFB.cpp:246): state symbol 4 = 'N' or LO/RO (always eq) matches every read
+// symbol, any other state symbol only itself — kept per position as a 32-bit mask over read symbols (mOwn)
 
 // exact ObservationModelFBMax::updateMax (ObservationModelFB.cpp:877-888) for the few special states
 __device__ __forceinline__ void update_max(double &dest, int &idx, int &code, double v, int newIdx, int newCode)
@@ -320,11 +320,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         eIn[k] = valid ? shE[x] : NEG_INF;          // Dec: logProbError[x]   (insertion-open into x)
         eInc[k] = (x + 1 <= RO) ? shE[x + 1] : NEG_INF;   // Inc: logProbError[x+1]
         niDec[k] = (x == 0) ? NEG_INF : NI;         // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
-        uint32_t mo = 0;
-#pragma unroll
-        for (int col = 0; col < 32; col++)
-            if (valid && code_match(sc[x], col)) mo |= 1u << col;
-        mOwn[k] = mo;
+        // bit c set <=> code_match(state symbol, c): 'N' / LO / RO match every column, another symbol its own, a pad none
+        const unsigned scode = sc[x];
+        mOwn[k] = !valid ? 0u : (scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u));
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
 

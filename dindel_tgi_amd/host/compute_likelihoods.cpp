@@ -361,6 +361,11 @@ double WindowLikelihoods::mLogBQ(size_t h, size_t r) const { return blk_->mLogBQ
 bool WindowLikelihoods::offHap(size_t h, size_t r) const { return blk_->offHap[pair(h, r)] != 0; }
 bool WindowLikelihoods::offHapHMQ(size_t h, size_t r) const { return blk_->offHapHMQ[pair(h, r)] != 0; }
 int WindowLikelihoods::numIndels(size_t h, size_t r) const { return blk_->numIndels[pair(h, r)]; }
+int WindowLikelihoods::indelCount(size_t h, size_t r) const
+{
+    if (!blk_->faster) return blk_->numIndels[pair(h, r)];
+    return int(get(h, r).indels.size());           // --faster: the map's size needs the walk over hpos
+}
 int WindowLikelihoods::numMismatch(size_t h, size_t r) const { return blk_->numMismatch[pair(h, r)]; }
 int WindowLikelihoods::nBQT(size_t h, size_t r) const { return blk_->nBQT[pair(h, r)]; }
 int WindowLikelihoods::nmmBQT(size_t h, size_t r) const { return blk_->nmmBQT[pair(h, r)]; }

@@ -48,6 +48,8 @@ public:
     bool offHap(size_t h, size_t r) const;
     bool offHapHMQ(size_t h, size_t r) const;
     int numIndels(size_t h, size_t r) const;      // == liks[h][r].indels.size() for the main model (one key per event)
+    int indelCount(size_t h, size_t r) const;     // liks[h][r].indels.size() for either model (the --faster model leaves numIndels 0
+                                                  // and may key several events at one position): what DInDel.cpp:3529 reads
     int numMismatch(size_t h, size_t r) const;
     int nBQT(size_t h, size_t r) const;
     int nmmBQT(size_t h, size_t r) const;

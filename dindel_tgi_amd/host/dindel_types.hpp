@@ -22,17 +22,23 @@ class AlignedVariant {
 public:
     enum Type { INS, DEL, SNP, REF };
     AlignedVariant() : type(REF), length(0), startHap(-1), endHap(-1), startRead(-1), endRead(-1),
-                       leftFlankHap(-1), rightFlankHap(-1), leftFlankRead(-1), rightFlankRead(-1) {}
+                       leftFlankHap(-1), rightFlankHap(-1), leftFlankRead(-1), rightFlankRead(-1), freq(-1.0), addComb(false) {}
     // "+SEQ" insertion, "-SEQ" deletion, "X=>Y" SNP — reference Variant.hpp:43-74
     AlignedVariant(const std::string &s, int _startHap, int _endHap, int _startRead, int _endRead)
         : str(s), startHap(_startHap), endHap(_endHap), startRead(_startRead), endRead(_endRead),
-          leftFlankHap(_startHap), rightFlankHap(_endHap), leftFlankRead(_startRead), rightFlankRead(_endRead)   // Variant.hpp:88-94
+          leftFlankHap(_startHap), rightFlankHap(_endHap), leftFlankRead(_startRead), rightFlankRead(_endRead),   // Variant.hpp:88-94
+          freq(-1.0), addComb(false)
     {
-        if (s.size() > 1 && s[0] == '-') { type = DEL; length = int(s.size()) - 1; seq = s.substr(1); }
-        else if (s.size() > 1 && s[0] == '+') { type = INS; length = int(s.size()) - 1; seq = s.substr(1); }
-        else if (s.size() == 4 && s[1] == '=' && s[2] == '>') { type = SNP; length = 1; seq = s; }
-        else if (s == "*REF") { type = REF; length = 1; seq = s; }           // Variant.hpp:62-65
-        else throw std::string("Unrecognized variant");
+        initFromString(s);
+    }
+    // a candidate variant of the window file: canonical position, prior / frequency, "add combinatorially" — Variant.hpp:100-121
+    AlignedVariant(const std::string &s, int canonicalPos, double _freq = -1.0, bool _addComb = false)
+        : str(s), startRead(-1), endRead(-1), leftFlankRead(-1), rightFlankRead(-1), freq(_freq), addComb(_addComb)
+    {
+        initFromString(s);
+        startHap = canonicalPos;
+        endHap = (type == DEL) ? startHap + length - 1 : startHap;
+        leftFlankHap = startHap; rightFlankHap = endHap;
     }
     const std::string &getString() const { return str; }
     const std::string &getSeq() const { return seq; }
@@ -40,6 +46,21 @@ public:
     int size() const { return length; }
     bool isIndel() const { return type == INS || type == DEL; }
     bool isSNP() const { return type == SNP; }
+    bool isRef() const { return type == REF; }
+    double getFreq() const { return freq; }
+    bool getAddComb() const { return addComb; }
+    // ordering inside std::set<AlignedVariant> — Variant.hpp:131-134
+    bool operator<(const AlignedVariant &v) const { return startHap != v.startHap ? startHap < v.startHap : str < v.str; }
+    // "is this the candidate (pos, type, string)?" — Variant.hpp:135-150: SNPs compare the "=>X" part, insertions the string,
+    // deletions only the length
+    bool isEqual(int pos, int _type, const std::string &_str) const
+    {
+        if (int(type) != _type || startHap != pos) return false;
+        if (_type == SNP) return _str.substr(1, 3) == str.substr(1, 3);
+        if (_type == INS) return str == _str;
+        if (_type == DEL) return str.size() == _str.size();
+        return false;
+    }
     int getStartHap() const { return startHap; }
     int getEndHap() const { return endHap; }
     int getStartRead() const { return startRead; }
@@ -56,12 +77,22 @@ public:
         return firstBase + pad <= startRead && lastBase - pad >= endRead;
     }
 private:
+    void initFromString(const std::string &s)          // Variant.hpp:43-74
+    {
+        if (s.size() > 1 && s[0] == '-') { type = DEL; length = int(s.size()) - 1; seq = s.substr(1); }
+        else if (s.size() > 1 && s[0] == '+') { type = INS; length = int(s.size()) - 1; seq = s.substr(1); }
+        else if (s.size() == 4 && s[1] == '=' && s[2] == '>') { type = SNP; length = 1; seq = s; }
+        else if (s == "*REF") { type = REF; length = 1; seq = s; }           // Variant.hpp:62-65
+        else throw std::string("Unrecognized variant");
+    }
     Type type;
     std::string seq, str;
     int length;
     int startHap, endHap;     // position of the variant in the haplotype the read is aligned to
     int startRead, endRead;   // position of the variant in the read aligned to the haplotype
     int leftFlankHap, rightFlankHap, leftFlankRead, rightFlankRead;
+    double freq;
+    bool addComb;
 };
 
 class MLAlignment {
@@ -97,6 +128,19 @@ public:
     std::map<int, AlignedVariant> indels, snps;   // variants of this haplotype w.r.t. the reference sequence
     size_t size() const { return seq.size(); }
     const char &operator[](size_t i) const { return seq[i]; }
+    // reference Haplotype.hpp:254-270
+    int countIndels() const
+    {
+        int num = 0;
+        for (std::map<int, AlignedVariant>::const_iterator it = indels.begin(); it != indels.end(); ++it) if (it->second.isIndel()) num++;
+        return num;
+    }
+    int countSNPs() const
+    {
+        int num = 0;
+        for (std::map<int, AlignedVariant>::const_iterator it = snps.begin(); it != snps.end(); ++it) if (it->second.isSNP() && !it->second.isRef()) num++;
+        return num;
+    }
 };
 
 // Insert-size distribution of a sequencing library — reference Library.hpp:37-140: probs[d] = normalised histogram
@@ -120,7 +164,8 @@ private:
 class Read {
 public:
     Read() : mapQual(0.0), posStat(0.0, 1.0), pos(0), unmapped(false), reverse(false), mateReverse(false),
-             paired(false), mateUnmapped(false), mateSameTid(false), matePos(-1), mateLen(-1), library(NULL) {}
+             paired(false), mateUnmapped(false), mateSameTid(false), matePos(-1), mateLen(-1), library(NULL),
+             onReverseStrand(false), bamPos(0), bamMatePos(-1), endPos(1), poolID(-1) {}
     Haplotype seq;                       // read.seq.seq is the base string, as in the reference
     std::vector<double> qual;            // P(base correct) — reference Read.hpp:143-148
     double mapQual;                      // P(mapping correct) — reference Read.hpp:127-131
@@ -140,6 +185,23 @@ public:
     bool mateIsUnmapped() const { return mateUnmapped; }
     const Library &getLibrary() const { return *library; }
     void setAllQual(double v) { qual.assign(seq.size(), v); }
+    // what the window's read selection (DetInDel::getReads, DInDel.cpp:885-1262) reads from the BAM record behind the read
+    std::string qname;                   // bam1_qname
+    bool onReverseStrand;                // BAM flag 0x10 at construction (Read.hpp:167); getReads may reverse an unmapped read's sequence, not this
+    int32_t bamPos, bamMatePos;          // bam->core.pos, bam->core.mpos
+    uint32_t endPos;                     // getEndPos(): bam_calend, or pos + 1 without a CIGAR (Read.hpp:185-188)
+    int poolID;
+    uint32_t getEndPos() const { return endPos; }
+    int32_t getBAMMatePos() const { return bamMatePos; }
+    // reverse() / complement() — Read.hpp:209-227 (getReads applies both to an unmapped read on its mate's strand)
+    void complementSeq()
+    {
+        for (size_t i = 0; i < seq.seq.size(); i++) {
+            char &n = seq.seq[i];
+            if (n == 'A') n = 'T'; else if (n == 'T') n = 'A'; else if (n == 'C') n = 'G'; else if (n == 'G') n = 'C';
+        }
+    }
+    void reverseSeq() { seq.seq = std::string(seq.seq.rbegin(), seq.seq.rend()); }
     // Phred -> probability exactly as the BAM constructor does — reference Read.hpp:127-131, 143-148
     static double phredToProb(double phred);
 };

@@ -1,0 +1,362 @@
+// diploid_glf.cpp — see diploid_glf.hpp.  Line references are to the reference's DInDel.cpp.
+#include "diploid_glf.hpp"
+#include <cmath>
+#include <iostream>
+#include <set>
+#include <sstream>
+
+namespace dindel {
+
+void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read> &reads, const WindowLikelihoods &liks,
+                      std::vector<int> &filtered, std::map<PAV, VariantCoverage> &varCoverage, bool doFilter)
+{
+    const int numHaps = int(haps.size());
+    filtered = std::vector<int>(haps.size(), 0);
+    varCoverage.clear();
+    typedef std::map<int, AlignedVariant>::const_iterator It;
+    std::map<PAV, std::vector<std::set<int> > > hVarCoverage;                               // :1940-1944
+    for (int h = 0; h < numHaps; h++) {
+        std::set<int> selReads;                                                              // :1951-1955
+        for (size_t r = 0; r < reads.size(); r++)
+            if (!liks.offHapHMQ(size_t(h), r) && liks.numIndels(size_t(h), r) == 0) selReads.insert(int(r));
+        bool allCovered = true;
+        for (It it = haps[size_t(h)].indels.begin(); it != haps[size_t(h)].indels.end(); ++it) {
+            const AlignedVariant &av = it->second;
+            const PAV pav(it->first, av);
+            if (hVarCoverage.find(pav) == hVarCoverage.end()) hVarCoverage[pav] = std::vector<std::set<int> >(haps.size() * 2);
+            if (av.getType() == AlignedVariant::INS || av.getType() == AlignedVariant::DEL) {
+                bool covered = false;
+                for (std::set<int>::const_iterator rt = selReads.begin(); rt != selReads.end(); ++rt) {
+                    const int r = *rt;
+                    int strand = 0;                                                          // :1982-1987
+                    if (reads[size_t(r)].isUnmapped()) { if (!reads[size_t(r)].mateIsReverse()) strand = 1; }
+                    else { if (reads[size_t(r)].isReverse()) strand = 1; }
+                    if (liks.hapIndelFilterCovered(size_t(h), size_t(r), it->first)) {       // the device's test (:1989-2054)
+                        hVarCoverage[pav][size_t(h + strand * numHaps)].insert(r);
+                        covered = true;
+                    }
+                }
+                if (!covered) { allCovered = false; break; }                                 // :2060-2063
+            }
+        }
+        if (doFilter && !allCovered) filtered[size_t(h)] = 1;                                // :2068-2073
+    }
+    for (std::map<PAV, std::vector<std::set<int> > >::const_iterator it = hVarCoverage.begin(); it != hVarCoverage.end(); ++it) {
+        std::set<int> rf, rr;                                                                // :2088-2097
+        for (int h = 0; h < numHaps; h++) if (filtered[size_t(h)] != 1) {
+            rf.insert(it->second[size_t(h)].begin(), it->second[size_t(h)].end());
+            rr.insert(it->second[size_t(h + numHaps)].begin(), it->second[size_t(h + numHaps)].end());
+        }
+        varCoverage[it->first] = VariantCoverage(int(rf.size()), int(rr.size()));
+    }
+}
+
+double getPairPrior(const AlignedVariant &av1, const AlignedVariant &av2, int leftPos, const AlignedCandidates &candidateVariants, const DiploidParameters &params)
+{
+    std::set<AlignedVariant> vars;                                                           // :1837-1854
+    vars.insert(av1); vars.insert(av2);
+    double ll = 0.0;
+    for (std::set<AlignedVariant>::const_iterator vt = vars.begin(); vt != vars.end(); ++vt) {
+        const AlignedVariant &avar = *vt;
+        double lnf = 0.0;
+        const int type = avar.getType();
+        const AlignedVariant *av = candidateVariants.findVariant(avar.getStartHap() + leftPos, avar.getType(), avar.getString());
+        if (type == AlignedVariant::SNP) lnf = log(params.priorSNP);
+        else if (type == AlignedVariant::DEL || type == AlignedVariant::INS) lnf = log(params.priorIndel);
+        if (av == NULL) ll += lnf;
+        else { const double prior = av->getFreq(); if (prior < 0.0) ll += lnf; else ll += log(prior); }
+    }
+    return ll;
+}
+
+double getHaplotypePrior(const Haplotype &h1, const Haplotype &h2, int leftPos, const AlignedCandidates &candidateVariants, const DiploidParameters &params)
+{
+    double ll = 0.0;                                                                         // :1857-1927
+    typedef std::map<int, AlignedVariant>::const_iterator AVIt;
+    std::set<AlignedVariant> indels, snps;
+    const Haplotype *hs[2] = {&h1, &h2};
+    for (int i = 0; i < 2; i++)
+        for (AVIt it = hs[i]->indels.begin(); it != hs[i]->indels.end(); ++it)
+            if (it->second.getString().find("*REF") == std::string::npos && it->second.getString().find("=>") == std::string::npos) indels.insert(it->second);
+    for (int i = 0; i < 2; i++)
+        for (AVIt it = hs[i]->snps.begin(); it != hs[i]->snps.end(); ++it)
+            if (it->second.getString().find("*REF") == std::string::npos && it->second.getString().find("=>D") == std::string::npos) snps.insert(it->second);
+    const std::set<AlignedVariant> *sets[2] = {&indels, &snps};
+    for (int s = 0; s < 2; s++)                                                              // SNPs get priorIndel too, as written (:1899-1908)
+        for (std::set<AlignedVariant>::const_iterator vt = sets[s]->begin(); vt != sets[s]->end(); ++vt) {
+            const AlignedVariant *av = candidateVariants.findVariant(vt->getStartHap() + leftPos, vt->getType(), vt->getString());
+            if (av == NULL) ll += log(params.priorIndel);
+            else { const double prior = av->getFreq(); if (prior < 0.0) ll += log(params.priorIndel); else ll += log(prior); }
+        }
+    return ll;
+}
+
+void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &reads, const WindowLikelihoods &liks, uint32_t candPos,
+                uint32_t leftPos, uint32_t rightPos, OutputData &glfData, int index, const std::string &tid,
+                const AlignedCandidates &candidateVariants, const DiploidParameters &params, const std::string &program)
+{
+    const size_t nh = haps.size(), nr = reads.size();
+    std::vector<int> filtered(nh, 0);
+    std::map<PAV, VariantCoverage> varCoverage;
+    filterHaplotypes(haps, reads, liks, filtered, varCoverage, params.filterHaplotypes);        // :2941
+
+    std::vector<double> rl(nh * nr, 0.0);                                                    // :2943-2961
+    {
+        size_t idx = 0;
+        for (size_t r = 0; r < nr; r++)
+            for (size_t h = 0; h < nh; h++) rl[idx++] = liks.ll(h, r);
+    }
+    const int VARSNP = 1, VARINDEL = 2;
+    std::set<PAV> allVariants;
+    std::map<int, std::set<PAV> > allVariantsByPos;
+    typedef std::map<int, AlignedVariant>::const_iterator It;
+    typedef std::map<int, std::set<PAV> >::const_iterator PIt;
+    std::vector<int> hap_num_indels(nh, 0), hap_num_candidate_indels(nh, 0), hap_num_snps(nh, 0);
+    for (size_t th = 0; th < nh; th++) {                                                     // :2982-3016
+        const Haplotype &hap = haps[th];
+        hap_num_indels[th] = hap.countIndels();
+        hap_num_snps[th] = hap.countSNPs();
+        if (hap_num_indels[th] != 0) {
+            int nc = 0;
+            for (It it = hap.indels.begin(); it != hap.indels.end(); ++it) {
+                const AlignedVariant &avar = it->second;
+                if (candidateVariants.findVariant(avar.getStartHap() + int(leftPos), avar.getType(), avar.getString()) != NULL) nc += 1;
+            }
+            hap_num_candidate_indels[th] = nc;
+        }
+        for (It it = hap.indels.begin(); it != hap.indels.end(); ++it)
+            if (!it->second.isRef() && !(it->second.isSNP() && it->second.getString()[3] == 'D')) {
+                allVariants.insert(PAV(it->first, it->second));
+                allVariantsByPos[it->first].insert(PAV(it->first, it->second));
+            }
+    }
+    std::map<int, int> posToPosIdx;                                                          // :3018-3026
+    {
+        int idx = 0;
+        for (PIt pit = allVariantsByPos.begin(); pit != allVariantsByPos.end(); ++pit) posToPosIdx[pit->first] = idx++;
+    }
+    const int numVarPos = int(allVariantsByPos.size());
+    const int nv = int(allVariants.size());
+    std::vector<int> hapVar(nh * size_t(numVarPos), 0), varType(size_t(nv) + 1);
+    std::vector<PAV> variants(size_t(nv) + 1);
+    {
+        int idx = 1;                                                                         // :3036-3050
+        for (std::set<PAV>::const_iterator pt = allVariants.begin(); pt != allVariants.end(); ++pt, ++idx) {
+            const PAV &pav = *pt;
+            varType[size_t(idx)] = pav.second.isIndel() ? VARINDEL : VARSNP;
+            const int posIdx = posToPosIdx[pav.first];
+            for (size_t h = 0; h < nh; h++) {
+                It it = haps[h].indels.find(pav.first);
+                if (it != haps[h].indels.end() && it->second.getString() == pav.second.getString()) hapVar[h * size_t(numVarPos) + size_t(posIdx)] = idx;
+            }
+            variants[size_t(idx)] = pav;
+        }
+    }
+    std::set<int> readidx;
+    for (size_t r = 0; r < nr; r++) readidx.insert(int(r));
+
+    std::vector<double> prior(nh * nh, 0.0), pairs_posterior(nh * nh, 0);                    // :3068-3075
+    for (size_t h1 = 0; h1 < nh; h1++)
+        for (size_t h2 = h1; h2 < nh; h2++) prior[h1 * nh + h2] = getHaplotypePrior(haps[h1], haps[h2], int(leftPos), candidateVariants, params);
+
+    std::vector<int> max_indel_pair(2, -1), max_noindel_pair(2, -1);
+    double max_ll_indel = -HUGE_VAL, max_ll_noindel = -HUGE_VAL;
+    for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3083-3114
+        double ll = 0.0;
+        for (size_t r = 0; r < nr; r++) ll += log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
+        pairs_posterior[h1 * nh + h2] = ll + prior[h1 * nh + h2];
+        const double pp = pairs_posterior[h1 * nh + h2];
+        if (pp > max_ll_indel && (hap_num_candidate_indels[h1] > 0 || hap_num_candidate_indels[h2] > 0)) { max_ll_indel = pp; max_indel_pair[0] = int(h1); max_indel_pair[1] = int(h2); }
+        if (pp > max_ll_noindel && (hap_num_candidate_indels[h1] == 0 && hap_num_candidate_indels[h2] == 0)) { max_ll_noindel = pp; max_noindel_pair[0] = int(h1); max_noindel_pair[1] = int(h2); }
+    }
+    const double ll_ref = max_ll_noindel;
+    const double qual = -10.0 * (ll_ref - addLogs(max_ll_indel, ll_ref)) / log(10.0);          // :3118
+    if (!params.quiet) std::cout << "ll_ref: " << ll_ref << " max_ll_indel: " << max_ll_indel << " qual: " << qual << std::endl;
+    if (max_indel_pair[0] == -1 || max_indel_pair[1] == -1) throw std::string("Could not find indel allele");   // :3121
+
+    {   // ---- map-based variant calls: one dip.map line per variant position of the MAP pair (:3122-3302) ----
+        int numUnmappedRealigned = 0;
+        const size_t hx1 = size_t(max_indel_pair[0]), hx2 = size_t(max_indel_pair[1]);
+        for (size_t r = 0; r < nr; r++)
+            if (reads[r].isUnmapped() && (liks.offHap(hx1, r) == false || liks.offHap(hx2, r) == false)) numUnmappedRealigned++;
+        std::map<int, std::set<AlignedVariant> > indels;
+        for (int i = 0; i < 2; i++) {
+            const Haplotype &hap = haps[size_t(max_indel_pair[size_t(i)])];
+            for (It it = hap.indels.begin(); it != hap.indels.end(); ++it)
+                if (!it->second.isRef() || (it->second.isSNP() && it->second.getString()[3] == 'D')) indels[it->first].insert(it->second);
+        }
+        for (std::map<int, std::set<AlignedVariant> >::const_iterator it = indels.begin(); it != indels.end(); ++it) {
+            double msq = 0;
+            int numf = 0, numr = 0, n = 0;
+            const int m = (max_indel_pair[0] == max_indel_pair[1]) ? 1 : 2;
+            for (int i = 0; i < m; i++) {
+                const size_t h = size_t(max_indel_pair[size_t(i)]);
+                It iter = haps[h].indels.find(it->first);
+                if (iter != haps[h].indels.end() && iter->second.isIndel()) {
+                    for (size_t r = 0; r < nr; r++) {
+                        bool nft = false, nrt = false;
+                        if (liks.hapIndelCovered(h, r, it->first)) {                          // :3158-3159
+                            if (reads[r].onReverseStrand) nrt = true; else nft = true;
+                            const double mq = -10 * log10(1.0 - reads[r].mapQual);
+                            msq += mq * mq;
+                            n++;
+                        }
+                        if (nft) numf++;
+                        if (nrt) numr++;
+                    }
+                }
+            }
+            if (n != 0) msq = sqrt(msq / double(n)); else msq = 0.0;
+            int was_candidate = 0;
+            const std::set<AlignedVariant> &alleles = it->second;
+            std::string genotype, nref_all;
+            std::set<std::string> all_genotype;
+            int vc_f = 0, vc_r = 0;
+            {
+                const AlignedVariant &avar = *alleles.begin();
+                if (candidateVariants.findVariant(avar.getStartHap() + int(leftPos), avar.getType(), avar.getString()) != NULL) was_candidate = 1;
+                vc_f += varCoverage[PAV(it->first, avar)].nf;
+                vc_r += varCoverage[PAV(it->first, avar)].nr;
+            }
+            std::string a1 = "*REF", a2 = "*REF";
+            bool a1_ref = true, a2_ref = true;
+            It ita1 = haps[hx1].indels.find(it->first), ita2 = haps[hx2].indels.find(it->first);
+            if (ita1 != haps[hx1].indels.end() && !ita1->second.isRef()) { a1 = ita1->second.getString(); a1_ref = false; }
+            if (ita2 != haps[hx2].indels.end() && !ita2->second.isRef()) { a2 = ita2->second.getString(); a2_ref = false; }
+            all_genotype.insert(a1);
+            all_genotype.insert(a2);
+            if (a1_ref && a2_ref) throw std::string("genotyping error");
+            if (a1 == a2) { genotype = "1/1"; nref_all = a1; }
+            else if (a1_ref) { genotype = "0/1"; nref_all = a2; }
+            else if (a2_ref) { genotype = "0/1"; nref_all = a1; }
+            else {
+                nref_all = a1 + ',' + a2;
+                genotype = "1/2";
+                const AlignedVariant &avar = *alleles.rbegin();
+                if (candidateVariants.findVariant(avar.getStartHap() + int(leftPos), avar.getType(), avar.getString()) != NULL) was_candidate = 1;
+                vc_f += varCoverage[PAV(it->first, avar)].nf;
+                vc_r += varCoverage[PAV(it->first, avar)].nr;
+            }
+            double max_ll_altgeno = -HUGE_VAL;                                               // genotype quality (:3238-3265)
+            for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {
+                if (!((h1 == hx1 && h2 == hx2) || (h2 == hx1 && h1 == hx2))) {
+                    std::set<std::string> alt_genotype;
+                    It it2 = haps[h1].indels.find(it->first);
+                    alt_genotype.insert((it2 == haps[h1].indels.end() || it2->second.isRef()) ? std::string("*REF") : it2->second.getString());
+                    it2 = haps[h2].indels.find(it->first);
+                    alt_genotype.insert((it2 == haps[h2].indels.end() || it2->second.isRef()) ? std::string("*REF") : it2->second.getString());
+                    if (alt_genotype != all_genotype && max_ll_altgeno < pairs_posterior[h1 * nh + h2]) max_ll_altgeno = pairs_posterior[h1 * nh + h2];
+                }
+            }
+            const double genoqual = -10.0 * (max_ll_altgeno - addLogs(max_ll_indel, max_ll_altgeno)) / log(10.0);
+            DipMapCall c;
+            c.index = index; c.tid = tid; c.leftPos = leftPos; c.rightPos = rightPos; c.candPos = candPos; c.realignedPos = it->first + int(leftPos);
+            c.was_candidate = was_candidate; c.qual = qual; c.nref_all = nref_all; c.num_reads = readidx.size(); c.msq = msq; c.numf = numf; c.numr = numr;
+            c.vc_f = vc_f; c.vc_r = vc_r; c.numUnmappedRealigned = numUnmappedRealigned; c.genotype = genotype; c.genoqual = genoqual;
+            glfData.output(dipMapLine(glfData, c));
+        }
+    }
+
+    // ---- per variant position: genotype likelihoods over the haplotype pairs, coverage and QC sums (:3305-3660) ----
+    for (PIt it = allVariantsByPos.begin(); it != allVariantsByPos.end(); ++it) {
+        int has_variants_in_window = 0;
+        for (std::set<PAV>::const_iterator pt = it->second.begin(); pt != it->second.end(); ++pt) {
+            const AlignedVariant &avar = pt->second;
+            if (candidateVariants.findVariant(avar.getStartHap() + int(leftPos), avar.getType(), avar.getString()) != NULL) { has_variants_in_window = 1; break; }
+        }
+        const double log5 = log(0.5);
+        int nf = 0, nrv = 0;
+        const int pos = it->first;
+        const int posIdx = posToPosIdx[pos];
+        double msq = 0.0;
+        int n = 0;
+        typedef std::set<int> IntGenotype;
+        std::map<IntGenotype, double> genLiks;
+        double maxll = -HUGE_VAL;
+        size_t hx1 = 0, hx2 = 0;
+        for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3347-3389
+            IntGenotype genotype;
+            const int v1 = hapVar[h1 * size_t(numVarPos) + size_t(posIdx)], v2 = hapVar[h2 * size_t(numVarPos) + size_t(posIdx)];
+            genotype.insert(v1);
+            genotype.insert(v2);
+            const AlignedVariant av1 = v1 ? variants[size_t(v1)].second : AlignedVariant("*REF", -1);
+            const AlignedVariant av2 = v2 ? variants[size_t(v2)].second : AlignedVariant("*REF", -1);
+            const double logPriorPos = getPairPrior(av1, av2, int(leftPos), candidateVariants, params);
+            const double pr = prior[h1 * nh + h2] - logPriorPos;       // the site's prior taken out again: a likelihood
+            double ll = pr;
+            for (size_t r = 0; r < nr; r++) ll += log5 + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
+            std::map<IntGenotype, double>::iterator igit = genLiks.find(genotype);
+            if (igit == genLiks.end()) genLiks[genotype] = ll; else genLiks[genotype] = addLogs(genLiks[genotype], ll);
+            if (ll > maxll) { maxll = ll; hx1 = h1; hx2 = h2; }
+        }
+        int numUnmappedRealigned = 0;                                                        // :3395-3402
+        for (size_t r = 0; r < nr; r++)
+            if (reads[r].isUnmapped() && (liks.offHap(hx1, r) == false || liks.offHap(hx2, r) == false)) numUnmappedRealigned++;
+        double allmsq = 0.0;                                                                 // :3492-3560
+        int numMappedIndels = 0, nBQT = 0, nmmBQT = 0, nMMLeft = 0, nMMRight = 0, numOffBoth = 0;
+        double mLogBQ = 0.0;
+        for (std::set<int>::const_iterator rt = readidx.begin(); rt != readidx.end(); ++rt) {
+            const size_t r = size_t(*rt);
+            const double mq = -10 * log10(1.0 - reads[r].mapQual);
+            allmsq += (mq * mq);
+            if (liks.offHap(hx1, r) && liks.offHap(hx2, r)) numOffBoth++;
+            const size_t h = (liks.ll(hx1, r) >= liks.ll(hx2, r)) ? hx1 : hx2;                // the read's better haplotype of the pair
+            bool nrt = false, nft = false, covered = false;
+            numMappedIndels += liks.indelCount(h, r);                                        // liks[h][r].indels.size(), :3529
+            nBQT += liks.nBQT(h, r);
+            nmmBQT += liks.nmmBQT(h, r);
+            mLogBQ += liks.mLogBQ(h, r);
+            if (liks.nMMLeft(h, r) >= 2) nMMLeft++;
+            if (liks.nMMRight(h, r) >= 2) nMMRight++;
+            It hit = haps[h].indels.find(pos);
+            if (hit != haps[h].indels.end()) {
+                if (hit->second.isIndel()) covered = liks.hapIndelCovered(h, r, pos);
+                else if (hit->second.isSNP()) covered = liks.hapSNPCovered(h, r, pos);
+            }
+            if (covered) {
+                if (reads[r].onReverseStrand) nrt = true; else nft = true;
+                const double mq2 = -10 * log10(1.0 - reads[r].mapQual);
+                msq += mq2 * mq2;
+                n++;
+            }
+            if (nft) nf++;
+            if (nrt) nrv++;
+        }
+        if (n != 0) msq = sqrt(msq / double(n)); else msq = 0.0;
+        allmsq = (readidx.size() != 0) ? sqrt(allmsq / double(readidx.size())) : 0;
+        std::map<int, int> toVCFidx;                                                         // :3572-3595
+        int nidx = 1;
+        toVCFidx[0] = 0;
+        std::ostringstream oAlleles, oCovForward, oCovReverse;
+        int first = 1;
+        for (size_t h = 0; h < nh; h++) {
+            const int v = hapVar[h * size_t(numVarPos) + size_t(posIdx)];
+            if (v != 0 && toVCFidx.find(v) == toVCFidx.end()) {
+                toVCFidx[v] = nidx++;
+                const std::string str = (first == 1) ? std::string("") : std::string(",");
+                oAlleles << str << variants[size_t(v)].second.getString();
+                oCovForward << str << varCoverage[variants[size_t(v)]].nf;
+                oCovReverse << str << varCoverage[variants[size_t(v)]].nr;
+                first = 0;
+            }
+        }
+        std::ostringstream o;                                                                // :3600-3613
+        first = 1;
+        for (std::map<IntGenotype, double>::iterator git = genLiks.begin(); git != genLiks.end(); ++git) {
+            const int a1 = toVCFidx[*(git->first.begin())], a2 = toVCFidx[*(git->first.rbegin())];
+            o << ((first == 1) ? "" : ",") << a1 << "/" << a2 << ":" << git->second;
+            first = 0;
+        }
+        if (params.outputGLF) {
+            DipPositionRow d;
+            d.index = index; d.tid = tid; d.program = program; d.leftPos = leftPos; d.rightPos = rightPos; d.candPos = candPos; d.realignedPos = pos + int(leftPos);
+            d.has_variants_in_window = has_variants_in_window; d.logZ = maxll; d.nBQT = nBQT; d.nmmBQT = nmmBQT; d.mLogBQ = mLogBQ; d.nMMLeft = nMMLeft;
+            d.nMMRight = nMMRight; d.nref_all = oAlleles.str(); d.num_reads = readidx.size(); d.msq = allmsq; d.numOffAll = numOffBoth; d.num_indel = numMappedIndels;
+            d.nf = nf; d.nr = nrv; d.var_coverage_forward = oCovForward.str(); d.var_coverage_reverse = oCovReverse.str(); d.glf = o.str();
+            d.numUnmappedRealigned = numUnmappedRealigned;
+            glfData.output(dipPositionLine(glfData, d));
+        }
+    }
+}
+
+} // namespace dindel

@@ -1,0 +1,50 @@
+// get_reads.hpp — the window's read selection: DetInDel::getReads restated on the own BAM reader.
+//   Read(const bam1_t*, ...)            reference Read.hpp:120-183   Phred -> probabilities, position statistics, library lookup
+//   Read::fetchFuncVectorPooled         reference Read.hpp:388-412   duplicates / QC-fail / supplementary records dropped
+//   DetInDel::getReads                  reference DInDel.cpp:885-1262 read buffer over consecutive windows, mate pairing, filters,
+//                                                                     sort by mapping quality, maxReads cap
+#ifndef DINDEL_GET_READS_HPP
+#define DINDEL_GET_READS_HPP
+#include <string>
+#include <vector>
+#include "bam_reader.hpp"
+#include "dindel_types.hpp"
+#include "window_io.hpp"
+
+namespace dindel {
+
+struct ReadSelectionParameters {         // the DetInDel::Parameters fields getReads looks at (CLI defaults: DInDel.cpp:4122-4157)
+    ReadSelectionParameters() : maxReads(10000), maxReadLength(500), minReadOverlap(20), mapQualThreshold(0.99), mapUnmappedReads(false), quiet(true) {}
+    size_t maxReads; size_t maxReadLength; int minReadOverlap; double mapQualThreshold; bool mapUnmappedReads; bool quiet;
+};
+
+// Read(const bam1_t *b, libraries, poolID, header, overrideLibName) — reference Read.hpp:120-183.  Throws std::string("Phred error.")
+// or std::string("Cannot find library: NAME").
+Read makeRead(const BamRecord &b, const BamFile &bam, const LibraryCollection &libraries, int poolID, const std::string &overrideLibName = std::string());
+
+// Read::computePositionStatistics — reference Read.hpp:261-306
+std::pair<double, double> computePositionStatistics(const BamRecord &b);
+
+class ReadFetcher {
+public:
+    ReadFetcher(std::vector<BamFile *> &bams, const LibraryCollection &libs, const ReadSelectionParameters &p)
+        : myBams(bams), libraries(libs), params(p), oldLeftPos(0), oldRightFetchReadPos(0), resetReadBuffer(true) {}
+    // DetInDel::getReads for the next window of chromosome `tid` (windows must come sorted by leftPos, as in the reference).
+    // Throws the reference's strings: "Choose a larger width or a smaller minReadOverlap.", "Too many reads in region",
+    // "duplicate reads!", "too_few_reads", "above_read_count_threshold".
+    void getReads(const std::string &tid, uint32_t leftPos, uint32_t rightPos, std::vector<Read> &reads);
+    // what detectIndels does around the call (DInDel.cpp:1327-1333, :1401-1408): a new chromosome or a skipped window resets the buffer
+    void newChromosome() { resetReadBuffer = true; oldLeftPos = 0; }
+    void windowDone(bool skipped, uint32_t leftPos) { resetReadBuffer = skipped; oldLeftPos = leftPos; }
+    uint32_t previousLeftPos() const { return oldLeftPos; }
+private:
+    std::vector<BamFile *> &myBams;
+    const LibraryCollection &libraries;
+    ReadSelectionParameters params;
+    std::vector<Read> readBuffer;
+    uint32_t oldLeftPos, oldRightFetchReadPos;
+    bool resetReadBuffer;
+};
+
+} // namespace dindel
+#endif

@@ -528,3 +528,117 @@ int ddh_glf_demo(const char *path, const char *thrown, const double *vals)
 }
 
 } // extern "C"
+
+// ---- N2: readers and the window's read selection ----
+#include "bam_reader.hpp"
+#include "get_reads.hpp"
+#include "window_io.hpp"
+
+extern "C" {
+
+// every record bam_fetch would hand over for (tid name, [beg, end)), as JSON; with beg < 0 the whole file sequentially
+int ddh_bam_fetch_json(const char *path, const char *tid, int beg, int end, char *out, int cap)
+{
+    try {
+        BamFile bam(path);
+        std::ostringstream os;
+        os << "{\"targets\":[";
+        for (size_t i = 0; i < bam.targetNames().size(); i++) os << (i ? "," : "") << "[\"" << bam.targetNames()[i] << "\"," << bam.targetLengths()[i] << "]";
+        os << "],\"records\":[";
+        bool first = true;
+        auto emitRec = [&](const BamRecord &b) -> bool {
+            os << (first ? "" : ",") << "{\"qname\":\"" << b.qname << "\",\"tid\":" << b.tid << ",\"pos\":" << b.pos << ",\"flag\":" << b.flag << ",\"mapq\":" << int(b.qual)
+               << ",\"mtid\":" << b.mtid << ",\"mpos\":" << b.mpos << ",\"isize\":" << b.isize << ",\"end\":" << b.endPos() << ",\"seq\":\"" << b.seq << "\",\"qual\":[";
+            for (size_t i = 0; i < b.qualities.size(); i++) os << (i ? "," : "") << int(b.qualities[i]);
+            os << "],\"cigar\":[";
+            for (size_t i = 0; i < b.cigar.size(); i++) os << (i ? "," : "") << b.cigar[i];
+            const char *lib = bam.getLibrary(b);
+            os << "],\"lib\":" << (lib ? std::string("\"") + lib + "\"" : std::string("null")) << "}";
+            first = false;
+            return true;
+        };
+        if (beg < 0) { BamRecord b; while (bam.next(b)) emitRec(b); }
+        else bam.fetch(bam.getTID(tid), beg, end, emitRec);
+        os << "]}";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// the window file and the library file as the driver sees them
+int ddh_parse_inputs_json(const char *varFile, int oneBased, const char *libFile, char *out, int cap)
+{
+    try {
+        std::ostringstream os;
+        os.precision(17);
+        os << "{\"windows\":[";
+        if (varFile && *varFile) {
+            VariantFile vf(varFile);
+            bool first = true;
+            while (!vf.eof()) {
+                AlignedCandidates c = vf.getLineVector(oneBased != 0);
+                if (c.variants.empty()) continue;
+                os << (first ? "" : ",") << "{\"tid\":\"" << c.tid << "\",\"leftPos\":" << c.leftPos << ",\"rightPos\":" << c.rightPos << ",\"centerPos\":" << c.centerPos << ",\"variants\":[";
+                for (size_t i = 0; i < c.variants.size(); i++)
+                    os << (i ? "," : "") << "[" << c.variants[i].getStartHap() << ",\"" << c.variants[i].getString() << "\"," << c.variants[i].getEndHap() << "," << c.variants[i].getFreq()
+                       << "," << int(c.variants[i].getAddComb()) << "]";
+                os << "]}";
+                first = false;
+            }
+        }
+        os << "],\"libraries\":{";
+        LibraryCollection libs;
+        if (libFile && *libFile) libs.addFromFile(libFile);
+        bool first = true;
+        for (LibraryCollection::const_iterator it = libs.begin(); it != libs.end(); ++it, first = false)
+            os << (first ? "" : ",") << "\"" << it->first << "\":[" << it->second.getMaxInsertSize() << "," << it->second.getNinetyFifthPctProb() << "," << it->second.getProb(0) << ","
+               << it->second.getProb(it->second.getMaxInsertSize() / 2) << "]";
+        os << "},\"maxInsertSize\":" << libs.getMaxInsertSize() << "}";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// DetInDel::getReads over consecutive windows (win: n x {leftPos, rightPos}); prm: {maxReads, maxReadLength, minReadOverlap,
+// mapUnmappedReads}; per window the selected reads in order, or the string thrown
+int ddh_get_reads_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
+                       char *out, int cap)
+{
+    try {
+        BamFile bam(bamPath);
+        std::vector<BamFile *> bams(1, &bam);
+        LibraryCollection libs;
+        if (libFile && *libFile) libs.addFromFile(libFile);
+        ReadSelectionParameters p;
+        p.maxReads = size_t(prm[0]); p.maxReadLength = size_t(prm[1]); p.minReadOverlap = prm[2]; p.mapUnmappedReads = prm[3] != 0; p.mapQualThreshold = mapQualThreshold;
+        ReadFetcher f(bams, libs, p);
+        std::ostringstream os;
+        os.precision(17);
+        os << "[";
+        for (int w = 0; w < n; w++) {
+            std::vector<Read> reads;
+            os << (w ? "," : "");
+            bool skipped = false;
+            try {
+                f.getReads(tid, uint32_t(win[2 * w]), uint32_t(win[2 * w + 1]), reads);
+                os << "{\"reads\":[";
+                for (size_t r = 0; r < reads.size(); r++)
+                    os << (r ? "," : "") << "[\"" << reads[r].qname << "\"," << int32_t(reads[r].pos) << "," << reads[r].mapQual << "," << reads[r].matePos << "," << reads[r].mateLen << ","
+                       << int(reads[r].isUnmapped()) << ",\"" << reads[r].seq.seq << "\"," << reads[r].posStat.first << "]";
+                os << "]}";
+            } catch (std::string &e) {
+                os << "{\"throw\":\"" << e << "\"}";
+                skipped = true;
+            }
+            f.windowDone(skipped, uint32_t(win[2 * w]));
+        }
+        os << "]";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,72 @@
+// window_io.hpp — the text inputs of the window loop: the realignment-window ("variants") file, the
+// library insert-size file and — in place of the reference's candidate-haplotype construction, which is out of this
+// repository's scope — a haplotype fixture file.
+//   AlignedCandidates, VariantFile::getLineVector     reference VariantFile.hpp:38-70, :188-289
+//   LibraryCollection (addFromFile, getMaxInsertSize)  reference Library.hpp:135-253
+#ifndef DINDEL_WINDOW_IO_HPP
+#define DINDEL_WINDOW_IO_HPP
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+#include "dindel_types.hpp"
+
+namespace dindel {
+
+// one realignment window with its candidate variants — reference VariantFile.hpp:38-70
+class AlignedCandidates {
+public:
+    AlignedCandidates() : centerPos(0), leftPos(0), rightPos(0) {}
+    AlignedCandidates(const std::string &_tid, const std::vector<AlignedVariant> &_variants, int _leftPos, int _rightPos)
+        : variants(_variants), tid(_tid), leftPos(_leftPos), rightPos(_rightPos) { centerPos = leftPos + (rightPos - leftPos) / 2; }
+    std::vector<AlignedVariant> variants;
+    std::string tid;
+    int centerPos, leftPos, rightPos;
+    const AlignedVariant *findVariant(int pos, int type, const std::string &str) const
+    {
+        for (size_t x = 0; x < variants.size(); x++) if (variants[x].isEqual(pos, type, str)) return &variants[x];
+        return NULL;
+    }
+};
+
+// the window file: "tid leftPos rightPos pos,variant[,prior[,addCombinatorially]] ..." per line — VariantFile.hpp:188-289
+class VariantFile {
+public:
+    explicit VariantFile(const std::string &fileName);     // throws std::string("Cannot open variant file ...")
+    bool eof() { return fin.eof(); }
+    // the next window; an AlignedCandidates without variants for an empty or unparsable line (the caller skips those).
+    // Throws std::string("Cannot read left boundary of region.") like the reference.
+    AlignedCandidates getLineVector(bool isOneBased = false);
+private:
+    std::ifstream fin;
+    int index;
+};
+
+// reference Library.hpp:135-253: name -> Library; "single_end" (a flat 2000-bin library) always exists
+class LibraryCollection : public std::map<std::string, Library> {
+public:
+    LibraryCollection();
+    void addFromFile(const std::string &fileName);        // "#LIB name" headers followed by "insertSize count" lines
+    double getMaxInsertSize() const;
+};
+
+// Candidate haplotypes of one window as DetInDel::getHaplotypes would leave them (DInDel.cpp:1526-1645): the block bounds it
+// settled on and, per haplotype, the sequence and its variants against the reference (Haplotype::indels / ::snps with read /
+// flank coordinates).  Text format, one record per line:
+//   W <index> <leftPos> <rightPos>
+//   H <sequence>
+//   V I|S <key> <string> <startHap> <endHap> <startRead> <endRead> <leftFlankHap> <rightFlankHap> <leftFlankRead> <rightFlankRead>
+struct WindowHaplotypes {
+    int index; uint32_t leftPos, rightPos;
+    std::vector<Haplotype> haps;
+};
+class HaplotypeFixture {
+public:
+    explicit HaplotypeFixture(const std::string &fileName);
+    const WindowHaplotypes *find(int index) const;        // NULL: no haplotypes given for that window
+private:
+    std::map<int, WindowHaplotypes> windows;
+};
+
+} // namespace dindel
+#endif

@@ -1,0 +1,182 @@
+"""N2 end to end on the GPU: `dindel_gpu` (host/dindel_gpu.cpp: detectIndels restated as prepare-N / compute / reduce-N) turns a
+BAM this test writes, a window file and a haplotype fixture into a .glf.txt; `dindel_glf2vcf` turns that into a VCF.
+Checked: the planted heterozygous deletion is called (genotype, allele, position, candidate flag); `qual` and the genotype
+quality equal a recomputation from the ORACLE's log-likelihoods of the same reads (DInDel.cpp:3083-3118, :3238-3268) to the
+six digits the table prints; windows that cannot be processed get the reference's skipped line; preparing windows ahead in
+batches gives byte-identical output to one window at a time; the --faster model runs through the same loop.
+Parity unpinned beyond the oracle comparison: the reference has no fixtures for the window loop."""
+import ctypes as C
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dindel_tgi_amd import capi, hostlib
+from tests import _bamwriter as bw
+from tests import _oracle
+from tests.test_glf_vcf_cpu import GLF_COLUMNS, write_fasta
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dindel_tgi_amd", "host")
+
+
+def add_logs(a, b):
+    return a + math.log(1.0 + math.exp(b - a)) if a > b else b + math.log(1.0 + math.exp(a - b))
+
+
+@pytest.fixture(scope="module")
+def scene(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("n2")
+    rng = np.random.default_rng(77)
+    r = list(rng.choice(list("ACGT"), 12000))
+    for i in range(3, len(r)):                     # no homopolymer longer than 3: the VCF's hp filter stays out of the picture
+        if r[i] == r[i - 1] == r[i - 2] == r[i - 3]:
+            r[i] = "ACGT"[("ACGT".index(r[i]) + 1 + i % 3) % 4]
+    ref = "".join(r)
+    fasta = str(tmp / "ref.fa")
+    write_fasta(fasta, [("20", ref)])
+    windows, fixture, recs = [], [], []
+    rid = 0
+    # three windows with a heterozygous 2-bp deletion at offset 60, one homozygous 3-bp insertion, one window whose reference
+    # haplotype is too short (hapSize error.), one without reads
+    # (windows sit right of position 2,200: getReads fetches from leftPos - maxInsertSize - 200 in unsigned arithmetic, DInDel.cpp:928)
+    spec = [(5000, "del", 0.5), (5400, "del", 0.5), (5800, "ins", 1.0), (6200, "del", 0.5), (6600, "short", 0.5), (9000, "empty", 0.0)]
+    for wi, (left, kind, frac) in enumerate(spec, start=1):
+        right = left + 120
+        hap0 = ref[left:right + 1]
+        if kind == "ins":
+            insseq = "GAT"
+            alt = ref[:left + 60] + insseq + ref[left + 60:]
+            hap1 = hap0[:60] + insseq + hap0[60:]
+            var = "+" + insseq
+            v1 = "V I 60 %s 60 60 60 62 60 60 59 63" % var           # inserted bases 60..62 of the haplotype, flanked by 59 | 63
+        else:
+            alt = ref[:left + 60] + ref[left + 62:]
+            hap1 = hap0[:60] + hap0[62:]
+            var = "-" + hap0[60:62]
+            v1 = "V I 60 %s 60 61 59 60 60 61 59 60" % var            # deletion between haplotype bases 59 | 60
+        windows.append("20 %d %d %d,%s" % (left, right, left + 60, var))
+        if kind == "short":
+            fixture += ["W %d %d %d" % (wi, left, right), "H ACG", "V I 60 *REF 60 60 60 60 60 60 60 60", "H " + hap1, v1]
+        else:
+            fixture += ["W %d %d %d" % (wi, left, right), "H " + hap0, "V I 60 *REF 60 60 60 60 60 60 60 60", "V S 60 *REF 60 60 60 60 60 60 60 60",
+                        "H " + hap1, v1, "V S 60 *REF 60 60 60 60 60 60 60 60"]
+        if kind == "empty":
+            continue
+        for _ in range(40):
+            from_alt = rng.random() < frac
+            p = int(rng.integers(left - 60, left + 75))
+            if from_alt:
+                cut = left + 60 - p                                     # read bases before the event
+                if kind == "ins":
+                    seq = alt[p:p + 100]
+                    cigar = "100M" if cut <= 0 or cut >= 97 else "%dM3I%dM" % (cut, 97 - cut)
+                    if cut <= 0:
+                        continue
+                else:
+                    seq = alt[p:p + 100]
+                    cigar = "100M" if cut <= 0 or cut >= 100 else "%dM2D%dM" % (cut, 100 - cut)
+                    if cut <= 0:
+                        p2 = p + 2                                      # a read right of the deletion sits two bases further on the reference
+                        seq, p = alt[p:p + 100], p2
+            else:
+                seq, cigar = ref[p:p + 100], "100M"
+            s = list(seq)
+            if rng.random() < 0.1:
+                k = int(rng.integers(0, 100)); s[k] = "ACGT"[("ACGT".index(s[k]) + 1) % 4]
+            recs.append(dict(qname="q%04d" % rid, flag=int(rng.choice([0, 16])), pos=p, mapq=60, cigar=cigar, seq="".join(s), qual=[30] * 100,
+                             mtid=-1, mpos=-1, isize=0, tags={}))
+            rid += 1
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp / "reads.bam")
+    bw.write_bam(bam, "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:12000\n", [("20", 12000)], [(0, r) for r in recs])
+    vf, hf = str(tmp / "windows.txt"), str(tmp / "haps.txt")
+    open(vf, "w").write("\n".join(windows) + "\n")
+    open(hf, "w").write("\n".join(fixture) + "\n")
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return dict(tmp=tmp, ref=ref, fasta=fasta, bam=bam, vf=vf, hf=hf, spec=spec)
+
+
+def run_driver(scene, prefix, *extra):
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = str(scene["tmp"] / prefix)
+    subprocess.check_call([os.path.join(HOST, "dindel_gpu"), "--bamFile", scene["bam"], "--varFile", scene["vf"], "--hapFile", scene["hf"],
+                           "--outputFile", out, "--quiet", *extra], env=env, stderr=subprocess.DEVNULL)
+    lines = open(out + ".glf.txt").read().split("\n")
+    assert lines[0].split(" ") == GLF_COLUMNS
+    return out + ".glf.txt", [dict(zip(GLF_COLUMNS, l.split(" "))) for l in lines[1:] if l]
+
+
+def test_driver_calls_match_oracle_recomputation(scene):
+    path, rows = run_driver(scene, "a", "--batchWindows", "64")
+    by_index = {}
+    for r in rows:
+        by_index.setdefault(int(r["index"]), []).append(r)
+    # windows 5 / 6: skipped lines with the reference's messages (DInDel.cpp:1366-1395), coordinates of the window FILE
+    assert [r["msg"] for r in by_index[5]] == ["error_hapSize_error."] and by_index[5][0]["lpos"] == "6600"
+    assert [r["msg"] for r in by_index[6]] == ["error_too_few_reads"] and by_index[6][0]["analysis_type"] == "NA"
+    lib = hostlib.load()
+    lib.ddh_get_reads_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_char_p, C.c_int]
+    p = capi.params_cli_defaults()
+    hap_lines = open(scene["hf"]).read().split("\n")
+    for wi, (left, kind, _f) in enumerate(scene["spec"][:4], start=1):
+        dm = [r for r in by_index[wi] if r["analysis_type"] == "dip.map"]
+        dp = [r for r in by_index[wi] if r["analysis_type"] == "dip"]
+        assert len(dm) == 1 and len(dp) == 1 and dm[0]["msg"] == "ok", [(r["msg"], r["analysis_type"]) for r in by_index[wi]]
+        haps = [l[2:] for l in hap_lines[hap_lines.index("W %d %d %d" % (wi, left, left + 120)):][:7] if l.startswith("H ")]
+        out = C.create_string_buffer(1 << 24)
+        win = (C.c_int * 2)(left, left + 120)
+        prm = (C.c_int * 4)(10000, 500, 20, 0)
+        assert lib.ddh_get_reads_json(scene["bam"].encode(), b"", b"20", win, 1, prm, 0.99, out, len(out)) > 0
+        reads = json.loads(out.value.decode())[0]["reads"]
+        # the oracle on the reads the window selected, in their order
+        ll = [[_oracle.pair(h, r[6], [phred_q] * len(r[6]), r[2], int(r[7]), left, p, unmapped=bool(r[5]))[0].ll for r in reads]
+              for h in haps for phred_q in [1.0 - 10 ** -3.0]]
+        pp = {}
+        for h1, h2 in ((0, 0), (0, 1), (1, 1)):
+            s = 0.0
+            for r in range(len(reads)):
+                s += math.log(0.5) + add_logs(ll[h1][r], ll[h2][r])
+            pp[(h1, h2)] = s + (0.0 if (h1, h2) == (0, 0) else math.log(1.0 / 10000.0))      # one candidate indel without a prior: log(priorIndel)
+        ll_ref = pp[(0, 0)]
+        best = max(((0, 1), (1, 1)), key=lambda k: pp[k])
+        qual = -10.0 * (ll_ref - add_logs(pp[best], ll_ref)) / math.log(10.0)
+        alt_best = max(v for k, v in pp.items() if k != best)            # every other pair has a different genotype at this site
+        genoqual = -10.0 * (alt_best - add_logs(pp[best], alt_best)) / math.log(10.0)
+        row = dm[0]
+        assert row["qual"] == "%g" % qual and row["glf"] == "%s:%g" % ("0/1" if best == (0, 1) else "1/1", genoqual), (wi, row["qual"], qual)
+        assert best == ((1, 1) if kind == "ins" else (0, 1))
+        assert row["realigned_position"] == str(left + 60) and row["was_candidate_in_window"] == "1" and row["num_reads"] == str(len(reads))
+        assert row["nref_all"] == ("+GAT" if kind == "ins" else "-" + scene["ref"][left + 60:left + 62])
+        assert int(row["var_coverage_forward"]) + int(row["var_coverage_reverse"]) > 5
+        assert dp[0]["nref_all"] == row["nref_all"] and int(dp[0]["nBQT"]) > 1000 and dp[0]["numOffAll"] == "0"
+        assert dp[0]["glf"].count(":") == 3                            # 0/0, 0/1, 1/1 log-likelihoods
+
+
+def test_driver_batching_is_exact_and_vcf_follows(scene):
+    a = open(run_driver(scene, "b1", "--batchWindows", "1")[0]).read()
+    b = open(run_driver(scene, "b64", "--batchWindows", "64")[0]).read()
+    c = open(run_driver(scene, "b2", "--batchWindows", "2")[0]).read()
+    assert a == b == c
+    lst = str(scene["tmp"] / "glfs.txt")
+    open(lst, "w").write(str(scene["tmp"] / "b64.glf.txt") + "\n")
+    vcf = str(scene["tmp"] / "calls.vcf")
+    subprocess.check_call([os.path.join(HOST, "dindel_glf2vcf"), "-i", lst, "-o", vcf, "-r", scene["fasta"], "-s", "S1"], stdout=subprocess.DEVNULL)
+    body = [l.split("\t") for l in open(vcf).read().split("\n") if l and not l.startswith("#")]
+    assert [(l[0], int(l[1])) for l in body] == [("20", 5060), ("20", 5460), ("20", 5860), ("20", 6260)]
+    ref = scene["ref"]
+    assert body[0][3] == ref[5059:5062] and body[0][4] == ref[5059] and body[0][9].startswith("0/1:")        # deletion: REF 3 bases, ALT the anchor
+    assert body[2][3] == ref[5859] and body[2][4] == ref[5859] + "GAT" and body[2][9].startswith("1/1:")   # insertion
+    assert all(l[6] == "PASS" for l in body)
+
+
+def test_driver_faster_model_runs_the_same_loop(scene):
+    _path, rows = run_driver(scene, "f", "--faster")
+    dm = [r for r in rows if r["analysis_type"] == "dip.map"]
+    assert [int(r["index"]) for r in dm] == [1, 2, 3, 4] and all(float(r["qual"]) > 20 for r in dm)
+    assert [r["msg"] for r in rows if r["index"] == "5"] == ["error_hapSize_error."]
