@@ -11,7 +11,11 @@ FILES = ["include/dindel_hmm.h", "oracle/dd_oracle.c", "oracle/dd_oracle.h", "or
          "dindel_tgi_amd/csrc/hmm_kernel.hip", "dindel_tgi_amd/csrc/faster_kernel.hip", "dindel_tgi_amd/csrc/genotype_kernel.hip",
          "dindel_tgi_amd/csrc/capi.cpp", "dindel_tgi_amd/host/compute_likelihoods.hpp", "dindel_tgi_amd/host/compute_likelihoods.cpp",
          "dindel_tgi_amd/host/genotype.hpp", "dindel_tgi_amd/host/genotype.cpp", "dindel_tgi_amd/host/cigar.hpp",
-         "dindel_tgi_amd/host/cigar.cpp", "dindel_tgi_amd/host/dindel_types.hpp"]
+         "dindel_tgi_amd/host/cigar.cpp", "dindel_tgi_amd/host/dindel_types.hpp", "dindel_tgi_amd/host/glf_output.hpp",
+         "dindel_tgi_amd/host/glf_to_vcf.hpp", "dindel_tgi_amd/host/glf_to_vcf.cpp", "dindel_tgi_amd/host/bam_reader.hpp",
+         "dindel_tgi_amd/host/window_io.hpp", "dindel_tgi_amd/host/window_io.cpp", "dindel_tgi_amd/host/get_reads.hpp",
+         "dindel_tgi_amd/host/get_reads.cpp", "dindel_tgi_amd/host/diploid_glf.hpp", "dindel_tgi_amd/host/diploid_glf.cpp",
+         "dindel_tgi_amd/host/dindel_gpu.cpp", "dindel_tgi_amd/host/dindel_glf2vcf.cpp", "tests/_vcf_oracle.py", "profiles/r02/instruction_mix.md"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
@@ -25,6 +29,10 @@ def test_reference_citations_point_inside_the_files():
     for f in os.listdir(pydir) if os.path.isdir(pydir) else []:
         if os.path.isfile(os.path.join(pydir, f)):
             nlines["python/" + f] = sum(1 for _ in open(os.path.join(pydir, f), errors="ignore"))
+    utils = os.path.join(pydir, "utils")
+    for f in os.listdir(utils) if os.path.isdir(utils) else []:      # python/utils/Fasta.py is cited as "Fasta.py:…" / "python/utils/Fasta.py:…"
+        if os.path.isfile(os.path.join(utils, f)) and f not in nlines:
+            nlines[f] = sum(1 for _ in open(os.path.join(utils, f), errors="ignore"))
     pat = re.compile(r"((?:python/)?[A-Za-z][A-Za-z0-9_]*\.(?:cpp|hpp|py|h))`?:(\d+)(?:-(\d+))?")
     bad, n = [], 0
     for rel in FILES:
