@@ -15,6 +15,17 @@ const int kLidxShift = 14;
 }
 
 // ---------------- BGZF ----------------
+BgzfReader::BgzfReader() : f(NULL), blockAddress(-1), blockLength(0), nextAddress(0), block(NULL), offset(0), cacheNext(0), zs(NULL)
+{
+    for (int i = 0; i < kCachedBlocks; i++) { cache[i].address = -1; cache[i].next = 0; cache[i].length = 0; }
+}
+
+BgzfReader::~BgzfReader()
+{
+    if (f) fclose(f);
+    if (zs) { inflateEnd(static_cast<z_stream *>(zs)); delete static_cast<z_stream *>(zs); }
+}
+
 void BgzfReader::open(const std::string &path)
 {
     f = fopen(path.c_str(), "rb");
@@ -24,38 +35,53 @@ void BgzfReader::open(const std::string &path)
 
 bool BgzfReader::loadBlock(int64_t address)
 {
+    for (int i = 0; i < kCachedBlocks; i++) if (cache[i].address == address) {
+        blockAddress = address; blockLength = cache[i].length; nextAddress = cache[i].next; block = cache[i].data.data(); offset = 0;
+        return true;
+    }
     uint8_t hdr[18];
     if (fseek(f, long(address), SEEK_SET) != 0) return false;
     if (fread(hdr, 1, 18, f) != 18) return false;
     if (hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) throw std::string("not a BGZF block");
     const int xlen = le16(hdr + 10);
     // extra subfields: find 'B','C' (the first one in every BGZF file: hdr[12..17] when xlen == 6)
-    std::vector<uint8_t> extra(size_t(xlen), 0);
-    memcpy(extra.data(), hdr + 12, size_t(std::min(xlen, 6)));
-    if (xlen > 6 && fread(extra.data() + 6, 1, size_t(xlen - 6), f) != size_t(xlen - 6)) return false;
     int bsize = -1;
-    for (int i = 0; i + 4 <= xlen;) {
-        const int slen = le16(extra.data() + i + 2);
-        if (extra[size_t(i)] == 'B' && extra[size_t(i + 1)] == 'C' && slen == 2) bsize = le16(extra.data() + i + 4);
-        i += 4 + slen;
+    if (xlen == 6 && hdr[12] == 'B' && hdr[13] == 'C' && le16(hdr + 14) == 2) bsize = le16(hdr + 16);
+    else {
+        std::vector<uint8_t> extra(size_t(xlen), 0);
+        memcpy(extra.data(), hdr + 12, size_t(std::min(xlen, 6)));
+        if (xlen > 6 && fread(extra.data() + 6, 1, size_t(xlen - 6), f) != size_t(xlen - 6)) return false;
+        for (int i = 0; i + 4 <= xlen;) {
+            const int slen = le16(extra.data() + i + 2);
+            if (extra[size_t(i)] == 'B' && extra[size_t(i + 1)] == 'C' && slen == 2) bsize = le16(extra.data() + i + 4);
+            i += 4 + slen;
+        }
     }
     if (bsize < 0) throw std::string("BGZF block without a BC field");
     const int clen = bsize - xlen - 19;                   // compressed payload; then CRC32 and ISIZE
     if (clen < 0) throw std::string("corrupt BGZF block");
-    std::vector<uint8_t> comp(size_t(clen) + 8);
+    comp.resize(size_t(clen) + 8);
     if (fread(comp.data(), 1, comp.size(), f) != comp.size()) return false;
     const uint32_t isize = le32(comp.data() + clen + 4);
-    block.resize(isize ? isize : 1);
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) throw std::string("zlib: inflateInit2 failed");
-    zs.next_in = comp.data(); zs.avail_in = uInt(clen);
-    zs.next_out = block.data(); zs.avail_out = uInt(isize);
-    const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END) throw std::string("zlib: corrupt BGZF block");
-    if (isize && uint32_t(crc32(crc32(0L, Z_NULL, 0), block.data(), isize)) != le32(comp.data() + clen)) throw std::string("BGZF block: CRC mismatch");
-    blockAddress = address; blockLength = int(isize); nextAddress = address + bsize + 1; offset = 0;
+    CachedBlock &C = cache[cacheNext];
+    C.address = -1;                                       // not valid while it is being filled (an exception leaves it so)
+    if (C.data.size() < (isize ? isize : 1)) C.data.resize(isize ? isize : 1);
+    if (isize) {
+        if (!zs) {
+            z_stream *z = new z_stream;
+            memset(z, 0, sizeof(*z));
+            if (inflateInit2(z, -15) != Z_OK) { delete z; throw std::string("zlib: inflateInit2 failed"); }
+            zs = z;
+        } else if (inflateReset(static_cast<z_stream *>(zs)) != Z_OK) throw std::string("zlib: inflateReset failed");
+        z_stream *z = static_cast<z_stream *>(zs);
+        z->next_in = comp.data(); z->avail_in = uInt(clen);
+        z->next_out = C.data.data(); z->avail_out = uInt(isize);
+        if (inflate(z, Z_FINISH) != Z_STREAM_END) throw std::string("zlib: corrupt BGZF block");
+        if (uint32_t(crc32(crc32(0L, Z_NULL, 0), C.data.data(), isize)) != le32(comp.data() + clen)) throw std::string("BGZF block: CRC mismatch");
+    }
+    C.address = address; C.length = int(isize); C.next = address + bsize + 1;
+    cacheNext = (cacheNext + 1) % kCachedBlocks;
+    blockAddress = address; blockLength = int(isize); nextAddress = C.next; block = C.data.data(); offset = 0;
     return true;
 }
 
@@ -63,7 +89,7 @@ void BgzfReader::seek(uint64_t voffset)
 {
     const int64_t address = int64_t(voffset >> 16);
     const int within = int(voffset & 0xffff);
-    if (address != blockAddress) {
+    if (address != blockAddress || block == NULL) {
         if (!loadBlock(address)) { blockAddress = address; blockLength = 0; nextAddress = address; }
     }
     offset = within;
@@ -79,7 +105,7 @@ bool BgzfReader::read(void *dst, size_t n)
             if (blockLength == 0) { if (feof(f)) return false; continue; }   // empty block (the EOF marker, or padding)
         }
         const size_t take = std::min(n, size_t(blockLength - offset));
-        memcpy(out, block.data() + offset, take);
+        memcpy(out, block + offset, take);
         out += take; offset += int(take); n -= take;
         if (offset == blockLength && n == 0) {
             // like bgzf_tell after a read that ends exactly at a block boundary: point at the start of the next block
@@ -276,14 +302,18 @@ std::vector<BamFile::Chunk> BamFile::chunksFor(int tid, int ibeg, int iend) cons
     return off;
 }
 
-bool BamFile::next(BamRecord &b)
+bool BamFile::nextRaw(std::vector<uint8_t> &d)
 {
     uint8_t w[4];
     if (!bgzf.read(w, 4)) return false;
     const uint32_t block_size = le32(w);
     if (block_size < 32) throw std::string("corrupt BAM record");
-    std::vector<uint8_t> d(block_size);
-    if (!bgzf.read(d.data(), block_size)) return false;
+    d.resize(block_size);
+    return bgzf.read(d.data(), block_size);
+}
+
+void BamFile::decodeCore(const std::vector<uint8_t> &d, BamRecord &b)
+{
     b.tid = int32_t(le32(d.data())); b.pos = int32_t(le32(d.data() + 4));
     const uint32_t l_read_name = d[8];
     b.qual = d[9]; b.bin = le16(d.data() + 10);
@@ -293,15 +323,30 @@ bool BamFile::next(BamRecord &b)
     size_t o = 32;
     const size_t need = o + l_read_name + 4ull * n_cigar + (size_t(b.l_qseq) + 1) / 2 + size_t(b.l_qseq);
     if (b.l_qseq < 0 || need > d.size()) throw std::string("corrupt BAM record");
-    b.qname.assign(reinterpret_cast<const char *>(d.data() + o), l_read_name ? l_read_name - 1 : 0); o += l_read_name;
+    o += l_read_name;
     b.cigar.resize(n_cigar);
     for (uint32_t k = 0; k < n_cigar; k++, o += 4) b.cigar[k] = le32(d.data() + o);
+}
+
+void BamFile::decodeRest(const std::vector<uint8_t> &d, BamRecord &b)
+{
+    const uint32_t l_read_name = d[8];
+    size_t o = 32;
+    b.qname.assign(reinterpret_cast<const char *>(d.data() + o), l_read_name ? l_read_name - 1 : 0);
+    o += l_read_name + 4 * b.cigar.size();
     static const char nt16[] = "=ACMGRSVTWYHKDBN";               // bam_nt16_rev_table
     b.seq.resize(size_t(b.l_qseq));
     for (int32_t x = 0; x < b.l_qseq; x++) b.seq[size_t(x)] = nt16[(d[o + size_t(x >> 1)] >> ((~x & 1) << 2)) & 15];
     o += (size_t(b.l_qseq) + 1) / 2;
     b.qualities.assign(d.begin() + long(o), d.begin() + long(o) + b.l_qseq); o += size_t(b.l_qseq);
     b.aux.assign(d.begin() + long(o), d.end());
+}
+
+bool BamFile::next(BamRecord &b)
+{
+    if (!nextRaw(raw)) return false;
+    decodeCore(raw, b);
+    decodeRest(raw, b);
     return true;
 }
 

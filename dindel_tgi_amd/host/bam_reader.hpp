@@ -35,18 +35,26 @@ struct BamRecord {                       // bam1_t / bam1_core_t with the variab
 
 class BgzfReader {
 public:
-    BgzfReader() : f(NULL), blockAddress(-1), blockLength(0), offset(0) {}
-    ~BgzfReader() { if (f) fclose(f); }
+    BgzfReader();
+    ~BgzfReader();
     void open(const std::string &path);                  // throws std::string
     bool read(void *dst, size_t n);                      // false at end of file (or a short read)
     void seek(uint64_t voffset);
     uint64_t tell() const { return (uint64_t(blockAddress) << 16) | uint64_t(offset); }
 private:
+    // The windows of a run walk along the chromosome and each bam_fetch starts at its 16-kb bin's first chunk, so the same
+    // blocks are asked for again and again: the last few inflated blocks are kept (round robin).
+    enum { kCachedBlocks = 8 };
+    struct CachedBlock { int64_t address, next; int length; std::vector<uint8_t> data; };
     bool loadBlock(int64_t address);
     FILE *f;
     int64_t blockAddress; int blockLength; int64_t nextAddress;
-    std::vector<uint8_t> block;
+    const uint8_t *block;                                // the current block's bytes (inside cache[])
     int offset;
+    CachedBlock cache[kCachedBlocks];
+    int cacheNext;
+    std::vector<uint8_t> comp;
+    void *zs;                                            // z_stream, reset between blocks
     BgzfReader(const BgzfReader &); BgzfReader &operator=(const BgzfReader &);
 };
 
@@ -64,6 +72,16 @@ public:
     bool next(BamRecord &b);                             // sequential read at the current position (false at end of file)
     std::string fileName;
 private:
+    // One record, undecoded: fetch() looks at tid / pos / CIGAR only and decodes the rest (name, bases, qualities, tags) of
+    // the records it hands to the callback.
+    bool nextRaw(std::vector<uint8_t> &d);
+    static void decodeCore(const std::vector<uint8_t> &d, BamRecord &b);     // fixed fields + CIGAR
+    static void decodeRest(const std::vector<uint8_t> &d, BamRecord &b);
+    // Where the previous fetch on this reference met its first record ending behind its `beg`.  In a coordinate-sorted file
+    // every record in front of it ends at or before that `beg`, so a later fetch with the same or a larger `beg` cannot be
+    // handed any of them: it starts its scan there instead of at the head of the bin's chunk.
+    struct Resume { int tid, beg; uint64_t voffset; bool valid; Resume() : tid(-1), beg(0), voffset(0), valid(false) {} } resume;
+    std::vector<uint8_t> raw;
     struct Chunk { uint64_t beg, end; bool operator<(const Chunk &o) const { return beg < o.beg; } };
     struct RefIndex { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; };
     std::vector<Chunk> chunksFor(int tid, int beg, int end) const;
@@ -80,14 +98,25 @@ private:
 template <class F> void BamFile::fetch(int tid, int beg, int end, F callback)
 {
     const std::vector<Chunk> chunks = chunksFor(tid, beg, end);
+    const bool resumable = resume.valid && resume.tid == tid && beg >= resume.beg;
+    const uint64_t from = resumable ? resume.voffset : 0;
+    bool noted = false;
     BamRecord b;
     for (size_t i = 0; i < chunks.size(); i++) {
-        bgzf.seek(chunks[i].beg);
+        if (chunks[i].end <= from) continue;
+        bgzf.seek(chunks[i].beg < from ? from : chunks[i].beg);
         while (bgzf.tell() < chunks[i].end) {
-            if (!next(b)) return;
+            const uint64_t here = bgzf.tell();
+            if (!nextRaw(raw)) return;
+            decodeCore(raw, b);
             if (b.tid != tid || b.pos >= end) return;                    // past the region: the file is sorted
-            if (int(b.endPos()) > beg && b.pos < end)                    // is_overlap
-                if (!callback(b)) return;
+            if (int(b.endPos()) > beg) {
+                if (!noted) { resume.tid = tid; resume.beg = beg; resume.voffset = here; resume.valid = true; noted = true; }
+                if (b.pos < end) {                                       // is_overlap
+                    decodeRest(raw, b);
+                    if (!callback(b)) return;
+                }
+            }
         }
     }
 }

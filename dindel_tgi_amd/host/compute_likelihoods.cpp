@@ -471,9 +471,15 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     // The result block of an earlier call is reused when no view refers to it any more (its pages are mapped and, when
     // pinned, registered with the device already); otherwise a new one is made and the old one lives on with its views.
     for (int w = 0; w < W; w++) jobs[w].result = WindowLikelihoods();      // views of an earlier call held by these jobs
+    // A pipelined caller (dindel_gpu: batch k+1 computes while batch k reduces) keeps two or three blocks alive in turn,
+    // so a few are remembered.
     std::shared_ptr<BatchBlock> blk;
-    if (spare_ && spare_.use_count() == 1) blk = spare_; else blk = std::make_shared<BatchBlock>();
-    spare_ = blk;
+    for (size_t i = 0; i < spare_.size() && !blk; i++) if (spare_[i].use_count() == 1) blk = spare_[i];
+    if (!blk) {
+        blk = std::make_shared<BatchBlock>();
+        if (spare_.size() < 4) spare_.push_back(blk);
+        else spare_[size_t(spareNext_++ % 4)] = blk;
+    }
     if (!scratch_) scratch_ = std::make_shared<PackScratch>();
     BatchBlock &B = *blk;
     PackScratch &S = *scratch_;

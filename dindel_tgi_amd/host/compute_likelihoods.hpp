@@ -144,7 +144,8 @@ private:
     bool throwOnPositive_;
     int hostThreads_;
     bool keepAlignments_;
-    std::shared_ptr<BatchBlock> spare_;      // result block of an earlier call that nobody references any more: reused (warm pages)
+    std::vector<std::shared_ptr<BatchBlock> > spare_;   // result blocks of earlier calls; one nobody references any more is reused (warm pages)
+    unsigned spareNext_ = 0;
     std::shared_ptr<PackScratch> scratch_;   // the packed inputs' buffers, reused between calls
 };
 

@@ -6,22 +6,37 @@
 //            those (getHaplotypes, DInDel.cpp:1526-1645: HaplotypeDistribution, SeqAn alignment) — out of this repository's
 //            scope; they are read from a fixture file (window_io.hpp) instead;
 //   compute  LikelihoodEngine::computeLikelihoodsBatch over the N prepared windows (one launch sequence on the GPU);
-//   reduce   per window, in file order: diploidGLF (diploid_glf.cpp) -> the window's lines, or the skipped-window line with
-//            the message the reference would print ("error_" + what was thrown).
-// One BAM file: with a single pool the read buffer's reset after a skipped window (DInDel.cpp:1401-1408) does not change which
-// reads a window sees, so preparing windows ahead of their predecessors' likelihood step is exact.
+//   reduce   per window: diploidGLF (diploid_glf.cpp) -> the window's lines, or the skipped-window line with the message the
+//            reference would print ("error_" + what was thrown); lines are written in file order.
+// The stages run as a pipeline: the main thread reads the window file and cuts it into batches; --prepareThreads workers, each
+// with its own handle on the BAM file and its own read buffer, prepare whole batches side by side; one thread feeds the GPU in
+// batch order; one thread (with --reduceThreads helpers, each window into its own buffer) reduces and writes in window order.
+// One BAM file: with a single pool the read buffer's reset (after a skipped window in the reference, DInDel.cpp:1401-1408; at
+// the head of every batch here) does not change which reads a window sees — the buffer always holds the file's reads starting in
+// [leftPos - maxInsert - 200, rightPos + maxInsert), in file order — so preparing windows ahead of their predecessors'
+// likelihood step, and batches side by side, is exact.  (One counter does depend on the buffer's history: "Too many reads in
+// region" fires on buffer size + records fetched > 100 * maxRead, which at a batch's first window is counted as after a reset.)
 //
 // Options (names follow the reference's CLI, DInDel.cpp:4079-4170):
 //   --bamFile F --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
 //   [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
-//   [--maxHapReadProd N] [--batchWindows N] [--device D] [--quiet]
+//   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--reduceThreads N] [--device D] [--quiet]
+//   [--timing]        one "timing:" line on stdout with the busy time of each stage
+//   [--prepareOnly]   stop after the prepare stage (no likelihoods, no calls: profiling the read selection on a GPU-less host)
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
 #include "compute_likelihoods.hpp"
 #include "diploid_glf.hpp"
 #include "get_reads.hpp"
@@ -38,7 +53,49 @@ struct WindowTask {
     const std::vector<Haplotype> *haps;
     std::string message;                 // "ok" or the skipped message
     bool skipped;
+    std::string lines;                   // what the reduce stage wrote for this window
 };
+struct Batch {
+    long seq;                            // position in the file: batches are computed and written in this order
+    std::vector<WindowTask> tasks;
+    std::vector<WindowJob> jobs;
+    std::vector<size_t> jobOf;
+};
+typedef std::unique_ptr<Batch> BatchPtr;
+
+// hand-over between two pipeline stages: at most `cap` batches wait in it
+class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap), closed_(false) {}
+    bool push(BatchPtr &b)               // false: the consumer is gone
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return false;
+        q_.push_back(std::move(b));
+        cv_.notify_all();
+        return true;
+    }
+    bool pop(BatchPtr &b)                // false: closed and drained
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        b = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; cv_.notify_all(); }
+    void abort() { std::lock_guard<std::mutex> lk(m_); closed_ = true; q_.clear(); cv_.notify_all(); }
+private:
+    std::mutex m_; std::condition_variable cv_; std::deque<BatchPtr> q_; size_t cap_; bool closed_;
+};
+
+double seconds_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 }
 
 int main(int argc, char **argv)
@@ -48,7 +105,8 @@ int main(int argc, char **argv)
         std::string a = argv[i];
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
         a = a.substr(2);
-        if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid") opt[a] = "1";
+        if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" ||
+            a == "prepareOnly") opt[a] = "1";
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::cerr << "Option --" << a << " needs a value\n"; return 2; }
     }
@@ -57,6 +115,7 @@ int main(int argc, char **argv)
     for (const char *need : {"bamFile", "varFile", "hapFile", "outputFile"})
         if (!has(need)) { std::cerr << "Please specify --" << need << "\n"; return 1; }
     try {
+        const std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
         ObservationModelParameters obs;
         obs.setCLIDefaultValues();
         obs.pError = num("pError", obs.pError); obs.pMut = num("pMut", obs.pMut);
@@ -71,8 +130,12 @@ int main(int argc, char **argv)
         dip.priorSNP = num("priorSNP", dip.priorSNP); dip.priorIndel = num("priorIndel", dip.priorIndel);
         dip.filterHaplotypes = has("filterHaplotypes"); dip.quiet = has("quiet");
         const double maxHapReadProd = num("maxHapReadProd", 10000000.0);
-        const int batchWindows = int(num("batchWindows", 256));
-        const bool faster = has("faster"), oneBased = has("varFileIsOneBased");
+        const int batchWindows = std::max(1, int(num("batchWindows", 256)));
+        const bool faster = has("faster"), oneBased = has("varFileIsOneBased"), prepareOnly = has("prepareOnly");
+        unsigned hw = std::thread::hardware_concurrency();
+        if (!hw) hw = 1;
+        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(8u, std::max(1u, hw / 4))))));
+        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(8u, std::max(1u, hw / 2))))));
 
         LibraryCollection libraries;
         if (has("libFile")) {                    // the reference: --libFile switches mapUnmappedReads on (DInDel.cpp:4268-4272)
@@ -80,10 +143,8 @@ int main(int argc, char **argv)
             rsp.mapUnmappedReads = true;
             obs.mapUnmappedReads = true;
         }
-        BamFile bam(opt["bamFile"]);
-        std::vector<BamFile *> bams(1, &bam);
+        { BamFile probe(opt["bamFile"]); }       // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens
         HaplotypeFixture fixture(opt["hapFile"]);
-        ReadFetcher fetcher(bams, libraries, rsp);
         LikelihoodEngine engine(obs, int(num("device", 0)));
         engine.setThrowOnPositiveLikelihood(false);
 
@@ -92,88 +153,201 @@ int main(int argc, char **argv)
         if (!glfOutput.is_open()) throw std::string("Cannot open file ").append(glfFile).append(" for writing.");
         OutputData glfData = makeGLFOutputData(glfOutput);
         glfData.outputLine(glfData.headerString());                               // DInDel.cpp:1290-1291
+        const double t_setup = seconds_since(t_start);
 
-        VariantFile vf(opt["varFile"]);
-        int index = 0;
-        std::string oldTid("-1");
-        std::vector<WindowTask> batch;
         long nWindows = 0, nSkipped = 0;
-
-        auto flush = [&]() {
-            // ---- compute: every prepared window of the batch in one call ----
-            std::vector<WindowJob> jobs;
-            std::vector<size_t> jobOf(batch.size(), size_t(-1));
-            for (size_t i = 0; i < batch.size(); i++) if (!batch[i].skipped) {
-                WindowJob J;
-                J.haps = batch[i].haps; J.reads = &batch[i].reads; J.leftPos = batch[i].leftPos; J.rightPos = batch[i].rightPos;
-                jobOf[i] = jobs.size();
-                jobs.push_back(J);
-            }
-            if (!jobs.empty()) { if (faster) engine.computeLikelihoodsFasterBatch(jobs); else engine.computeLikelihoodsBatch(jobs); }
-            // ---- reduce, in window order ----
-            for (size_t i = 0; i < batch.size(); i++) {
-                WindowTask &T = batch[i];
-                if (!T.skipped) {
-                    const WindowJob &J = jobs[jobOf[i]];
-                    try {
-                        if (!J.error.empty()) throw std::string(J.error);
-                        // like the reference, diploidGLF writes its lines as it goes: if it throws half-way ("genotyping error"),
-                        // the lines already written stay and the skipped-window line follows them
-                        diploidGLF(*T.haps, T.reads, J.result, T.pos, T.leftPos, T.rightPos, glfData, T.index, T.tid, T.candidates, dip, "dip");
-                    } catch (std::string &s) {
-                        T.message = skippedMessage(s);
-                        T.skipped = true;
-                    }
-                }
-                if (T.skipped) {
-                    std::cerr << "skipped " << T.tid << " " << T.pos << " reason: " << T.message << std::endl;     // DInDel.cpp:1383
-                    glfData.output(skippedWindowLine(glfData, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
-                    nSkipped++;
-                }
-                nWindows++;
-            }
-            batch.clear();
+        double t_prepare = 0.0, t_compute = 0.0, t_pack = 0.0, t_device = 0.0, t_unpack = 0.0, t_reduce = 0.0;
+        std::mutex fatal_m;
+        std::string fatal;
+        Channel toPrepare(size_t(prepareThreads) + 1), toCompute(2), toReduce(2);
+        std::mutex order_m;
+        std::condition_variable order_cv;
+        long nextToCompute = 0;                  // the batch the compute stage takes next
+        bool orderAborted = false;
+        auto fail = [&](const std::string &s) {
+            { std::lock_guard<std::mutex> lk(fatal_m); if (fatal.empty()) fatal = s; }
+            toPrepare.abort(); toCompute.abort(); toReduce.abort();
+            { std::lock_guard<std::mutex> lk(order_m); orderAborted = true; }
+            order_cv.notify_all();
         };
 
-        while (!vf.eof()) {
-            AlignedCandidates cand = vf.getLineVector(oneBased);
-            if (cand.variants.size() == 0) continue;
-            WindowTask T;
-            T.candidates = cand; T.tid = cand.tid; T.pos = uint32_t(cand.centerPos);
-            T.fileLeftPos = T.leftPos = uint32_t(cand.leftPos); T.fileRightPos = T.rightPos = uint32_t(cand.rightPos);
-            T.haps = NULL; T.skipped = false; T.message = "ok";
-            if (T.tid != oldTid) {                                                  // DInDel.cpp:1327-1333
-                if (!batch.empty()) flush();
-                fetcher.newChromosome();
-                oldTid = T.tid;
-            }
-            if (T.fileLeftPos < fetcher.previousLeftPos()) {                          // :1335-1339
-                std::cerr << "leftPos: " << T.fileLeftPos << " oldLeftPos: " << fetcher.previousLeftPos() << std::endl;
-                std::cerr << "Candidate variant files must be sorted on left position of window!" << std::endl;
-                return 1;
-            }
-            T.index = ++index;
+        // ---- prepare: whole batches side by side, handed on in file order ----
+        std::vector<double> t_prepare_of(size_t(prepareThreads), 0.0);
+        std::vector<std::thread> prepareWorkers;
+        for (int pt = 0; pt < prepareThreads; pt++) prepareWorkers.push_back(std::thread([&, pt]() {
             try {
-                fetcher.getReads(T.tid, T.fileLeftPos, T.fileRightPos, T.reads);
-                const WindowHaplotypes *wh = fixture.find(T.index);
-                if (!wh) throw std::string("no haplotypes for this window in the haplotype file");
-                T.haps = &wh->haps; T.leftPos = wh->leftPos; T.rightPos = wh->rightPos;
-                if (double(T.reads.size() * T.haps->size()) > maxHapReadProd) {     // :395-399
-                    std::stringstream os;
-                    os << "skipped_numhap_times_numread>" << long(maxHapReadProd);
-                    throw os.str();
+                BamFile bam(opt["bamFile"]);
+                std::vector<BamFile *> bams(1, &bam);
+                ReadFetcher fetcher(bams, libraries, rsp);
+                BatchPtr b;
+                while (toPrepare.pop(b)) {
+                    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                    std::string oldTid;
+                    for (size_t i = 0; i < b->tasks.size(); i++) {
+                        WindowTask &T = b->tasks[i];
+                        if (i == 0 || T.tid != oldTid) { fetcher.newChromosome(); oldTid = T.tid; }     // DInDel.cpp:1327-1333
+                        try {
+                            fetcher.getReads(T.tid, T.fileLeftPos, T.fileRightPos, T.reads);
+                            const WindowHaplotypes *wh = fixture.find(T.index);
+                            if (!wh) throw std::string("no haplotypes for this window in the haplotype file");
+                            T.haps = &wh->haps; T.leftPos = wh->leftPos; T.rightPos = wh->rightPos;
+                            if (double(T.reads.size() * T.haps->size()) > maxHapReadProd) {     // :395-399
+                                std::stringstream os;
+                                os << "skipped_numhap_times_numread>" << long(maxHapReadProd);
+                                throw os.str();
+                            }
+                        } catch (std::string &s) {
+                            T.message = skippedMessage(s);
+                            T.skipped = true;
+                        }
+                        fetcher.windowDone(T.skipped, T.fileLeftPos);                         // :1401-1408
+                    }
+                    t_prepare_of[size_t(pt)] += seconds_since(t0);
+                    std::unique_lock<std::mutex> lk(order_m);
+                    const long seq = b->seq;
+                    order_cv.wait(lk, [&] { return nextToCompute == seq || orderAborted; });
+                    if (orderAborted) break;
+                    const bool ok = toCompute.push(b);
+                    nextToCompute = seq + 1;
+                    lk.unlock();
+                    order_cv.notify_all();
+                    if (!ok) break;
                 }
-            } catch (std::string &s) {
-                T.message = skippedMessage(s);
-                T.skipped = true;
+            } catch (std::string &s) { fail(s); }
+            catch (std::exception &e) { fail(e.what()); }
+        }));
+
+        // ---- compute: every prepared window of a batch in one call ----
+        std::thread computeThread([&]() {
+            BatchPtr b;
+            try {
+                while (toCompute.pop(b)) {
+                    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                    Batch &B = *b;
+                    B.jobOf.assign(B.tasks.size(), size_t(-1));
+                    for (size_t i = 0; i < B.tasks.size(); i++) if (!B.tasks[i].skipped) {
+                        WindowJob J;
+                        J.haps = B.tasks[i].haps; J.reads = &B.tasks[i].reads; J.leftPos = B.tasks[i].leftPos; J.rightPos = B.tasks[i].rightPos;
+                        B.jobOf[i] = B.jobs.size();
+                        B.jobs.push_back(J);
+                    }
+                    if (!B.jobs.empty() && !prepareOnly) {
+                        if (faster) engine.computeLikelihoodsFasterBatch(B.jobs); else engine.computeLikelihoodsBatch(B.jobs);
+                        t_pack += engine.lastPackSeconds; t_device += engine.lastDeviceSeconds; t_unpack += engine.lastUnpackSeconds;
+                    }
+                    t_compute += seconds_since(t0);
+                    if (!toReduce.push(b)) break;
+                }
+            } catch (std::string &s) { fail(s); }
+            catch (std::exception &e) { fail(e.what()); }
+            toReduce.close();
+        });
+
+        // ---- reduce: windows of a batch side by side, each into its own buffer; written out in window order ----
+        std::thread reduceThread([&]() {
+            BatchPtr b;
+            try {
+                while (toReduce.pop(b)) {
+                    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                    Batch &B = *b;
+                    std::atomic<size_t> next(0);
+                    auto work = [&]() {
+                        for (;;) {
+                            const size_t i = next.fetch_add(1);
+                            if (i >= B.tasks.size()) break;
+                            WindowTask &T = B.tasks[i];
+                            std::ostringstream os;
+                            OutputData local = glfData;
+                            local.out = &os;
+                            if (!T.skipped && !prepareOnly) {
+                                const WindowJob &J = B.jobs[B.jobOf[i]];
+                                try {
+                                    if (!J.error.empty()) throw std::string(J.error);
+                                    // like the reference, diploidGLF writes its lines as it goes: if it throws half-way ("genotyping
+                                    // error"), the lines already written stay and the skipped-window line follows them
+                                    diploidGLF(*T.haps, T.reads, J.result, T.pos, T.leftPos, T.rightPos, local, T.index, T.tid, T.candidates, dip, "dip");
+                                } catch (std::string &s) {
+                                    T.message = skippedMessage(s);
+                                    T.skipped = true;
+                                }
+                            }
+                            if (T.skipped) local.output(skippedWindowLine(local, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
+                            T.lines = os.str();
+                        }
+                    };
+                    std::vector<std::thread> pool;
+                    const int nt = int(std::min<size_t>(size_t(reduceThreads), B.tasks.size()));
+                    for (int t = 1; t < nt; t++) pool.push_back(std::thread(work));
+                    work();
+                    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+                    for (size_t i = 0; i < B.tasks.size(); i++) {
+                        const WindowTask &T = B.tasks[i];
+                        if (T.skipped) {
+                            std::cerr << "skipped " << T.tid << " " << T.pos << " reason: " << T.message << std::endl;     // DInDel.cpp:1383
+                            nSkipped++;
+                        }
+                        glfOutput << T.lines;
+                        nWindows++;
+                    }
+                    glfOutput.flush();
+                    b.reset();                                                    // drops the batch's views: its result block can be reused
+                    t_reduce += seconds_since(t0);
+                }
+            } catch (std::string &s) { fail(s); }
+            catch (std::exception &e) { fail(e.what()); }
+        });
+
+        // ---- the window file, in file order ----
+        int rc = 0;
+        try {
+            VariantFile vf(opt["varFile"]);
+            int index = 0;
+            long seq = 0;
+            std::string oldTid("-1");
+            uint32_t oldLeftPos = 0;
+            BatchPtr batch(new Batch);
+            auto flush = [&]() {
+                batch->seq = seq++;
+                const bool ok = toPrepare.push(batch);
+                batch.reset(new Batch);
+                return ok;
+            };
+            while (!vf.eof()) {
+                AlignedCandidates cand = vf.getLineVector(oneBased);
+                if (cand.variants.size() == 0) continue;
+                if (cand.tid != oldTid) { oldTid = cand.tid; oldLeftPos = 0; }                // DInDel.cpp:1327-1333
+                if (uint32_t(cand.leftPos) < oldLeftPos) {                                    // :1335-1339
+                    std::cerr << "leftPos: " << uint32_t(cand.leftPos) << " oldLeftPos: " << oldLeftPos << std::endl;
+                    std::cerr << "Candidate variant files must be sorted on left position of window!" << std::endl;
+                    rc = 1;
+                    break;
+                }
+                oldLeftPos = uint32_t(cand.leftPos);
+                batch->tasks.push_back(WindowTask());
+                WindowTask &T = batch->tasks.back();
+                T.candidates = cand; T.tid = cand.tid; T.pos = uint32_t(cand.centerPos);
+                T.fileLeftPos = T.leftPos = uint32_t(cand.leftPos); T.fileRightPos = T.rightPos = uint32_t(cand.rightPos);
+                T.haps = NULL; T.skipped = false; T.message = "ok";
+                T.index = ++index;
+                if (int(batch->tasks.size()) >= batchWindows && !flush()) break;
             }
-            fetcher.windowDone(T.skipped, T.fileLeftPos);                             // :1401-1408
-            batch.push_back(T);
-            if (int(batch.size()) >= batchWindows) flush();
-        }
-        if (!batch.empty()) flush();
+            if (!batch->tasks.empty()) flush();
+        } catch (std::string &s) { fail(s); }
+        toPrepare.close();
+        for (size_t t = 0; t < prepareWorkers.size(); t++) prepareWorkers[t].join();
+        for (size_t t = 0; t < t_prepare_of.size(); t++) t_prepare += t_prepare_of[t];
+        toCompute.close();
+        computeThread.join();
+        reduceThread.join();
         glfOutput.close();
+        if (!fatal.empty()) throw fatal;
+        if (rc) return rc;
         if (!has("quiet")) std::cout << "windows: " << nWindows << " skipped: " << nSkipped << " -> " << glfFile << std::endl;
+        if (has("timing")) {
+            const double wall = seconds_since(t_start);
+            std::cout << "timing: wall=" << wall << " setup=" << t_setup << " prepare_threads=" << prepareThreads << " prepare=" << t_prepare << " compute=" << t_compute << " (pack=" << t_pack
+                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce=" << t_reduce << " windows_per_s=" << double(nWindows) / wall << std::endl;
+        }
     } catch (std::string &s) {
         std::cerr << "Exception: " << s << std::endl;
         return 1;

@@ -3,8 +3,6 @@
 #include <algorithm>
 #include <cmath>
 #include <iostream>
-#include <list>
-#include <map>
 
 namespace dindel {
 
@@ -32,14 +30,34 @@ std::pair<double, double> computePositionStatistics(const BamRecord &b)
     return std::pair<double, double>(dmean + double(refPos), var);
 }
 
+namespace {
+// getLibraryName + the collection lookup of the Read constructor (Read.hpp:170-201)
+const Library *lookupLibrary(const BamRecord &b, const BamFile &bam, const LibraryCollection &libraries, const std::string &overrideLibName)
+{
+    std::string libName;
+    if (b.flag & BAM_FPAIRED) { const char *p = bam.getLibrary(b); libName = p ? std::string(p) : std::string("dindel_default"); }
+    else libName = "single_end";
+    LibraryCollection::const_iterator it = libraries.find(overrideLibName.empty() ? libName : overrideLibName);
+    if (it == libraries.end()) throw std::string("Cannot find library: ").append(libName);
+    return &it->second;
+}
+}
+
 Read makeRead(const BamRecord &b, const BamFile &bam, const LibraryCollection &libraries, int poolID, const std::string &overrideLibName)
 {
+    // Phred values are bytes: Read::phredToProb of each, once (0 marks an entry whose conversion throws "Phred error.")
+    static const std::vector<double> table = []() {
+        std::vector<double> t(256, 0.0);
+        for (int q = 0; q < 256; q++) { try { t[size_t(q)] = Read::phredToProb(double(q)); } catch (std::string &) { t[size_t(q)] = 0.0; } }
+        return t;
+    }();
+    struct Conv { static double prob(const std::vector<double> &t, uint8_t q) { const double v = t[q]; return v != 0.0 ? v : Read::phredToProb(double(q)); } };
     Read r;
-    r.mapQual = Read::phredToProb(double(b.qual));                   // Read.hpp:124-129
+    r.mapQual = Conv::prob(table, b.qual);                           // Read.hpp:124-129
     r.pos = uint32_t(b.pos);
     r.seq.seq = b.seq;
-    r.qual.reserve(b.qualities.size());
-    for (size_t x = 0; x < b.qualities.size(); x++) r.qual.push_back(Read::phredToProb(double(b.qualities[x])));     // :139-148
+    r.qual.resize(b.qualities.size());
+    for (size_t x = 0; x < b.qualities.size(); x++) r.qual[x] = Conv::prob(table, b.qualities[x]);                    // :139-148
     r.posStat = computePositionStatistics(b);
     r.unmapped = (b.flag & BAM_FUNMAP) != 0; r.paired = (b.flag & BAM_FPAIRED) != 0; r.mateUnmapped = (b.flag & BAM_FMUNMAP) != 0;
     r.reverse = (b.flag & BAM_FREVERSE) != 0; r.mateReverse = (b.flag & BAM_FMREVERSE) != 0; r.mateSameTid = b.tid == b.mtid;
@@ -48,17 +66,81 @@ Read makeRead(const BamRecord &b, const BamFile &bam, const LibraryCollection &l
     r.matePos = b.mpos;                                              // :169
     r.mateLen = -1;
     r.qname = b.qname; r.bamPos = b.pos; r.bamMatePos = b.mpos; r.endPos = b.endPos();
-    std::string libName;                                             // getLibraryName, :189-201
-    if (r.paired) { const char *p = bam.getLibrary(b); libName = p ? std::string(p) : std::string("dindel_default"); }
-    else libName = "single_end";
-    LibraryCollection::const_iterator it = libraries.find(overrideLibName.empty() ? libName : overrideLibName);
-    if (it == libraries.end()) throw std::string("Cannot find library: ").append(libName);
-    r.library = &it->second;
+    r.library = lookupLibrary(b, bam, libraries, overrideLibName);   // getLibraryName, :189-201
     return r;
 }
 
 namespace {
-bool byMapQualDescending(const Read &r1, const Read &r2) { return r1.mapQual > r2.mapQual; }     // :890-895
+// The selection below works on one small record per buffered read instead of on copies of the reads: the reference copies the
+// whole buffer (reads = readBuffer, :1055-1057), edits the copies, sorts them and keeps the head.  The buffer spans
+// 2 * maxInsert + 200 bases around the window and only a fraction of it overlaps the window, so here the edits go into
+// Selection records, those are sorted, and only the reads that are kept are copied.  std::sort is driven by the comparator's
+// answers alone, so sorting the records with the reference's comparator (mapQual descending, :890-895) leaves them in the
+// order it leaves the reads in.
+struct Selection { double mapQual; uint32_t idx; int32_t matePos, mateLen; bool flip; };
+bool byMapQualDescending(const Selection &r1, const Selection &r2) { return r1.mapQual > r2.mapQual; }
+
+uint64_t hashName(const std::string &s)
+{
+    uint64_t h = 1469598103934665603ull;                                                     // FNV-1a
+    for (size_t i = 0; i < s.size(); i++) { h ^= uint8_t(s[i]); h *= 1099511628211ull; }
+    return h;
+}
+
+// qname -> the buffer indices carrying it, ascending (what the reference keeps in two hash_map<string, list<int>>, :1063-1072)
+class NameIndex {
+public:
+    NameIndex(const std::vector<Read> &reads) : reads_(reads)
+    {
+        size_t cap = 16;
+        while (cap < 2 * reads.size()) cap <<= 1;
+        mask_ = cap - 1;
+        slot_.assign(cap, -1);
+        next_.assign(reads.size(), -1);
+        tail_.assign(reads.size(), -1);
+        count_.assign(reads.size(), 0);
+        hash_.resize(reads.size());
+        for (size_t r = 0; r < reads.size(); r++) {
+            const uint64_t h = hash_[r] = hashName(reads[r].qname);
+            size_t at = size_t(h) & mask_;
+            for (;;) {
+                const int head = slot_[at];
+                if (head < 0) { slot_[at] = int(r); tail_[r] = int(r); count_[r] = 1; break; }
+                if (hash_[size_t(head)] == h && reads[size_t(head)].qname == reads[r].qname) {
+                    next_[size_t(tail_[size_t(head)])] = int(r); tail_[size_t(head)] = int(r); count_[size_t(head)]++;
+                    break;
+                }
+                at = (at + 1) & mask_;
+            }
+        }
+    }
+    bool anyNameMoreThan(int n) const { for (size_t r = 0; r < count_.size(); r++) if (count_[r] > n) return true; return false; }
+    // first buffer index with this name (-1: none); walk the others with next()
+    int first(const std::string &qname) const
+    {
+        const uint64_t h = hashName(qname);
+        size_t at = size_t(h) & mask_;
+        for (;;) {
+            const int head = slot_[at];
+            if (head < 0) return -1;
+            if (hash_[size_t(head)] == h && reads_[size_t(head)].qname == qname) return head;
+            at = (at + 1) & mask_;
+        }
+    }
+    int next(int r) const { return next_[size_t(r)]; }
+    // calls f(idx) for every read called qname whose isUnmapped() == unmapped, ascending; returns how many there are
+    template <class F> int each(const std::string &qname, bool unmapped, F f) const
+    {
+        int n = 0;
+        for (int i = first(qname); i >= 0; i = next(i)) if (reads_[size_t(i)].isUnmapped() == unmapped) { n++; f(i); }
+        return n;
+    }
+private:
+    const std::vector<Read> &reads_;
+    size_t mask_;
+    std::vector<int> slot_, next_, tail_, count_;
+    std::vector<uint64_t> hash_;
+};
 }
 
 void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t rightPos, std::vector<Read> &reads)
@@ -68,9 +150,6 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
     reads.clear();
     if (int(rightPos - leftPos) < 3 * params.minReadOverlap) throw std::string("Choose a larger width or a smaller minReadOverlap.");
     const int maxDev = int(libraries.getMaxInsertSize());
-    typedef std::map<std::string, std::list<int> > NameIndex;
-    NameIndex mapped_name_to_idx, unmapped_name_to_idx;
-    NameIndex::const_iterator hash_it;
     int numUnknownLib = 0;
     const int LEFTPAD = 200;
     const uint32_t rightFetchReadPos = rightPos + uint32_t(maxDev);
@@ -82,14 +161,13 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         readBuffer.clear();
         oldRightFetchReadPos = rightFetchReadPos;
     } else {
-        std::vector<Read> kept;                                                              // :942-961
+        size_t keep = 0;                                                                     // :942-961
         for (size_t r = 0; r < readBuffer.size(); r++)
-            if (!(uint32_t(readBuffer[r].bamPos) < leftMostReadPos)) kept.push_back(readBuffer[r]);
-        readBuffer.swap(kept);
+            if (!(uint32_t(readBuffer[r].bamPos) < leftMostReadPos)) { if (keep != r) std::swap(readBuffer[keep], readBuffer[r]); keep++; }
+        readBuffer.resize(keep);
         if (leftMostReadPos < oldRightFetchReadPos) leftFetchReadPos = oldRightFetchReadPos;
     }
     int numReads = int(readBuffer.size());
-    std::vector<Read> newReads;
     if (leftFetchReadPos <= rightFetchReadPos) {                                             // :981-993
         for (size_t b = 0; b < myBams.size(); b++) {
             BamFile &bam = *myBams[b];
@@ -97,13 +175,18 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
             const int pool = int(b);
             bam.fetch(bam.getTID(tid), int(leftFetchReadPos), int(rightFetchReadPos), [&](const BamRecord &rec) -> bool {
                 if (!((rec.flag & BAM_FDUP) || (rec.flag & BAM_FQCFAIL) || (rec.flag & 0x800))) {              // Read.hpp:392
+                    // :998-1004: a read starting left of the fetched stretch was picked up by an earlier window; the reference
+                    // builds it and drops it afterwards.  Here it is counted and its library looked up (what can throw), not built.
+                    const bool wanted = uint32_t(rec.pos) >= leftFetchReadPos;
                     try {
-                        newReads.push_back(makeRead(rec, bam, libraries, pool));
+                        if (wanted) readBuffer.push_back(makeRead(rec, bam, libraries, pool));
+                        else lookupLibrary(rec, bam, libraries, std::string());
                         numReads++;
                     } catch (std::string &s) {
                         if (s.find("Cannot find library") == std::string::npos) throw;
                         numUnknownLib++;
-                        newReads.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
+                        if (wanted) readBuffer.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
+                        else lookupLibrary(rec, bam, libraries, "single_end");
                         numReads++;
                     }
                 }
@@ -113,25 +196,23 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         }
         oldRightFetchReadPos = rightFetchReadPos;
     }
-    for (size_t r = 0; r < newReads.size(); r++)                                             // :998-1004: reads overlapping the
-        if (uint32_t(newReads[r].bamPos) >= leftFetchReadPos) readBuffer.push_back(newReads[r]);   // boundary were picked up before
-    {                                                                                        // :1027-1044
-        std::map<std::string, int> qnameCount;
-        for (size_t r = 0; r < readBuffer.size(); r++)
-            if (++qnameCount[readBuffer[r].qname] > 2) throw std::string("duplicate reads!");
-    }
-    newReads.clear();
     const size_t oldNumReads = readBuffer.size();
-    reads = readBuffer;                                                                      // :1055-1057
-    for (size_t r = 0; r < reads.size(); r++) {                                              // :1063-1072
-        if (reads[r].isUnmapped()) unmapped_name_to_idx[reads[r].qname].push_back(int(r));
-        else mapped_name_to_idx[reads[r].qname].push_back(int(r));
+    const NameIndex names(readBuffer);
+    if (names.anyNameMoreThan(2)) throw std::string("duplicate reads!");                     // :1027-1044
+    // the reference's two indices (:1063-1072) are one here: a name's reads are walked in buffer order and told apart by
+    // isUnmapped()
+    const NameIndex &mates = names;
+    std::vector<Selection> sel(readBuffer.size());
+    for (size_t r = 0; r < sel.size(); r++) {
+        sel[r].mapQual = readBuffer[r].mapQual; sel[r].idx = uint32_t(r); sel[r].matePos = readBuffer[r].matePos; sel[r].mateLen = readBuffer[r].mateLen;
+        sel[r].flip = false;
     }
     int numTIDmismatch = 0, numOrphan = 0, numOrphanUnmapped = 0, numInRegion = 0;
     double minMapQual = params.mapQualThreshold;
     if (minMapQual < 0.0) minMapQual = 0.0;
-    for (int r = 0; r < int(reads.size()); r++) {                                            // :1095-1213
-        Read &rd = reads[size_t(r)];
+    for (int r = 0; r < int(readBuffer.size()); r++) {                                       // :1095-1213
+        const Read &rd = readBuffer[size_t(r)];
+        Selection &out = sel[size_t(r)];
         bool filter = false;
         if (rd.size() > params.maxReadLength) filter = true;
         if (rd.getEndPos() < leftMostReadPos || uint32_t(rd.pos) > rightMostReadPos) filter = true;
@@ -143,43 +224,37 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                 if (!rd.mateSameTid) {
                     numTIDmismatch++;
                 } else {
-                    hash_it = mapped_name_to_idx.find(rd.qname);
-                    if (hash_it == mapped_name_to_idx.end()) { numOrphan++; filter = true; }
-                    else {
-                        if (hash_it->second.size() > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
-                        filter = true;                                                       // :1125-1127 (mateIsUnmapped() == false here)
-                        for (std::list<int>::const_iterator li = hash_it->second.begin(); li != hash_it->second.end(); ++li) {
-                            const int idx = *li;
-                            if (idx != r) {
-                                rd.mateLen = int32_t(reads[size_t(idx)].size());
-                                rd.matePos = int32_t(reads[size_t(idx)].pos);
-                                filter = false;
-                                if (rd.matePos != rd.getBAMMatePos()) throw std::string("matepos inconsistency!");   // the reference exits
-                            }
+                    filter = true;                                                           // :1125-1127 (mateIsUnmapped() == false here)
+                    bool inconsistent = false;
+                    const int n = mates.each(rd.qname, false, [&](int idx) {
+                        if (idx != r) {
+                            out.mateLen = int32_t(readBuffer[size_t(idx)].size());
+                            out.matePos = int32_t(readBuffer[size_t(idx)].pos);
+                            filter = false;
+                            if (out.matePos != rd.getBAMMatePos()) inconsistent = true;
                         }
-                        if (filter == true) numOrphan++;
-                    }
+                    });
+                    if (n > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
+                    if (inconsistent) throw std::string("matepos inconsistency!");           // the reference exits
+                    if (filter == true) numOrphan++;                                         // (also when the name is not indexed, :1118-1121)
                 }
             } else {                                                                         // mate unmapped (:1148-1166)
-                rd.matePos = int32_t(rd.pos);
-                hash_it = unmapped_name_to_idx.find(rd.qname);
-                if (hash_it == unmapped_name_to_idx.end()) filter = true;
-                else {
-                    filter = true;
-                    if (hash_it->second.size() > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
-                    for (std::list<int>::const_iterator li = hash_it->second.begin(); li != hash_it->second.end(); ++li)
-                        if (*li != r) { rd.mateLen = int32_t(reads[size_t(*li)].size()); filter = false; }
-                }
+                out.matePos = int32_t(rd.pos);
+                filter = true;
+                const int n = mates.each(rd.qname, true, [&](int idx) {
+                    if (idx != r) { out.mateLen = int32_t(readBuffer[size_t(idx)].size()); filter = false; }
+                });
+                if (n > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
                 if (filter == true) numOrphan++;
             }
             if (filter == false) numInRegion++;
         } else if (params.mapUnmappedReads) {                                                // :1171-1209
-            hash_it = mapped_name_to_idx.find(rd.qname);
-            if (hash_it == mapped_name_to_idx.end()) { numOrphanUnmapped++; filter = true; }
+            int idx = -1;
+            const int n = mates.each(rd.qname, false, [&](int i) { if (idx < 0) idx = i; });
+            if (n == 0) { numOrphanUnmapped++; filter = true; }
             else {
-                if (hash_it->second.size() != 1) throw std::string("UNMAPPED READ HAS MORE THAN ONE MATE!");      // the reference exits
-                const int idx = *hash_it->second.begin();
-                const Read &mate = reads[size_t(idx)];
+                if (n != 1) throw std::string("UNMAPPED READ HAS MORE THAN ONE MATE!");      // the reference exits
+                const Read &mate = readBuffer[size_t(idx)];
                 const int maxInsert = mate.getLibrary().getMaxInsertSize(), minInsert = 0;
                 const uint32_t mpos = mate.pos;
                 uint32_t range_l, range_r;
@@ -188,25 +263,26 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                 if (range_r > leftPos && range_l < rightPos) {
                     numInRegion++;
                     filter = false;
-                    rd.mapQual = mate.mapQual;
-                    rd.matePos = int32_t(mate.pos);
-                    rd.mateLen = int32_t(mate.size());
-                    if (rd.isReverse() == mate.isReverse()) { rd.reverseSeq(); rd.complementSeq(); }
+                    out.mapQual = sel[size_t(idx)].mapQual;                                  // the mate's value as edited so far (-1 if it was filtered)
+                    out.matePos = int32_t(mate.pos);
+                    out.mateLen = int32_t(mate.size());
+                    if (rd.isReverse() == mate.isReverse()) out.flip = true;                 // reverse() + complement()
                 } else filter = true;
             }
         } else filter = true;
-        if (filter == true) rd.mapQual = -1.0;                                               // :1210
+        if (filter == true) out.mapQual = -1.0;                                              // :1210
     }
     int nUnmapped = 0, nMateposError = 0;
-    std::sort(reads.begin(), reads.end(), byMapQualDescending);                              // :1218
-    std::vector<Read> filteredReads;
-    for (size_t max = 0; max < params.maxReads && max < reads.size(); max++) {               // :1219-1227
-        if (reads[max].mapQual < minMapQual) break;
-        if (reads[max].matePos == -1 && reads[max].isPaired() && !reads[max].mateIsUnmapped()) { nMateposError++; reads[max].matePos = int32_t(reads[max].pos); }
-        filteredReads.push_back(reads[max]);
-        if (reads[max].isUnmapped()) nUnmapped++;
+    std::sort(sel.begin(), sel.end(), byMapQualDescending);                                  // :1218
+    for (size_t max = 0; max < params.maxReads && max < sel.size(); max++) {                 // :1219-1227
+        if (sel[max].mapQual < minMapQual) break;
+        reads.push_back(readBuffer[sel[max].idx]);
+        Read &rd = reads.back();
+        rd.mapQual = sel[max].mapQual; rd.matePos = sel[max].matePos; rd.mateLen = sel[max].mateLen;
+        if (sel[max].flip) { rd.reverseSeq(); rd.complementSeq(); }
+        if (rd.matePos == -1 && rd.isPaired() && !rd.mateIsUnmapped()) { nMateposError++; rd.matePos = int32_t(rd.pos); }
+        if (rd.isUnmapped()) nUnmapped++;
     }
-    filteredReads.swap(reads);
     if (!params.quiet)
         std::cout << "Number of reads: " << reads.size() << " out of " << oldNumReads << " # unmapped reads: " << nUnmapped << " numReadsUnknownLib: " << numUnknownLib
                   << " numChrMismatch: " << numTIDmismatch << " numMappedWithoutMate: " << numOrphan << " numUnmappedWithoutMate: " << numOrphanUnmapped << std::endl;

@@ -566,6 +566,27 @@ int ddh_bam_fetch_json(const char *path, const char *tid, int beg, int end, char
     }
 }
 
+// the names bam_fetch hands over for each of n regions (reg[2k], reg[2k+1]), all fetched on ONE handle, as a JSON list of lists
+int ddh_bam_fetch_seq_json(const char *path, const char *tid, const int *reg, int n, char *out, int cap)
+{
+    try {
+        BamFile bam(path);
+        const int t = bam.getTID(tid);
+        std::ostringstream os;
+        os << "[";
+        for (int k = 0; k < n; k++) {
+            os << (k ? "," : "") << "[";
+            bool first = true;
+            bam.fetch(t, reg[2 * k], reg[2 * k + 1], [&](const BamRecord &b) -> bool { os << (first ? "" : ",") << "\"" << b.qname << "\""; first = false; return true; });
+            os << "]";
+        }
+        os << "]";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
 // the window file and the library file as the driver sees them
 int ddh_parse_inputs_json(const char *varFile, int oneBased, const char *libFile, char *out, int cap)
 {

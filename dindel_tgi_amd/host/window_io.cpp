@@ -1,5 +1,6 @@
 // window_io.cpp — see window_io.hpp.
 #include "window_io.hpp"
+#include <cstdlib>
 #include <cmath>
 #include <iostream>
 #include <sstream>
@@ -154,33 +155,53 @@ HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
     std::string line;
     WindowHaplotypes *cur = NULL;
     int lineNo = 0;
+    std::vector<std::pair<const char *, size_t> > tok;                 // the line's blank-separated fields
     while (std::getline(fin, line)) {
         lineNo++;
         if (line.empty() || line[0] == '#') continue;
-        std::istringstream is(line);
-        std::string tag;
-        is >> tag;
-        std::ostringstream where;
-        where << " in line " << lineNo << " of " << fileName;
+        tok.clear();
+        for (size_t i = 0; i < line.size();) {
+            while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) i++;
+            const size_t st = i;
+            while (i < line.size() && !(line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) i++;
+            if (i > st) tok.push_back(std::make_pair(line.data() + st, i - st));
+        }
+        if (tok.empty()) continue;
+        auto bad = [&](const char *what) {
+            std::ostringstream where;
+            where << what << " in line " << lineNo << " of " << fileName;
+            return where.str();
+        };
+        auto integer = [&](size_t k, const char *what) -> long {      // field k as a whole decimal number
+            if (k >= tok.size()) throw bad(what);
+            const std::string t(tok[k].first, tok[k].second);
+            char *end = NULL;
+            const long v = strtol(t.c_str(), &end, 10);
+            if (end == t.c_str() || *end) throw bad(what);
+            return v;
+        };
+        const std::string tag(tok[0].first, tok[0].second);
         if (tag == "W") {
             WindowHaplotypes w;
-            if (!(is >> w.index >> w.leftPos >> w.rightPos)) throw std::string("Cannot read window record").append(where.str());
+            w.index = int(integer(1, "Cannot read window record"));
+            w.leftPos = uint32_t(integer(2, "Cannot read window record")); w.rightPos = uint32_t(integer(3, "Cannot read window record"));
             cur = &(windows[w.index] = w);
         } else if (tag == "H") {
-            std::string seq;
-            if (!cur || !(is >> seq)) throw std::string("Cannot read haplotype record").append(where.str());
-            cur->haps.push_back(Haplotype(seq));
+            if (!cur || tok.size() < 2) throw bad("Cannot read haplotype record");
+            cur->haps.push_back(Haplotype(std::string(tok[1].first, tok[1].second)));
         } else if (tag == "V") {
-            std::string kind, str;
-            int key, sh, eh, sr, er, lfh, rfh, lfr, rfr;
-            if (!cur || cur->haps.empty() || !(is >> kind >> key >> str >> sh >> eh >> sr >> er >> lfh >> rfh >> lfr >> rfr))
-                throw std::string("Cannot read variant record").append(where.str());
-            AlignedVariant av(str, sh, eh, sr, er);
-            av.setFlanking(lfh, rfh, lfr, rfr);
+            const char *what = "Cannot read variant record";
+            if (!cur || cur->haps.empty() || tok.size() < 12) throw bad(what);
+            const std::string kind(tok[1].first, tok[1].second), str(tok[3].first, tok[3].second);
+            const int key = int(integer(2, what));
+            int v[8];
+            for (size_t k = 0; k < 8; k++) v[k] = int(integer(4 + k, what));
+            AlignedVariant av(str, v[0], v[1], v[2], v[3]);
+            av.setFlanking(v[4], v[5], v[6], v[7]);
             if (kind == "I") cur->haps.back().indels[key] = av;
             else if (kind == "S") cur->haps.back().snps[key] = av;
-            else throw std::string("Variant record must say I or S").append(where.str());
-        } else throw std::string("Unknown record").append(where.str());
+            else throw bad("Variant record must say I or S");
+        } else throw bad("Unknown record");
     }
 }
 

@@ -163,6 +163,10 @@ def test_driver_batching_is_exact_and_vcf_follows(scene):
     b = open(run_driver(scene, "b64", "--batchWindows", "64")[0]).read()
     c = open(run_driver(scene, "b2", "--batchWindows", "2")[0]).read()
     assert a == b == c
+    # batches prepared side by side (each worker with its own BAM handle and read buffer) and reduced on several threads
+    d = open(run_driver(scene, "b2p", "--batchWindows", "2", "--prepareThreads", "4", "--reduceThreads", "3")[0]).read()
+    e = open(run_driver(scene, "b1p", "--batchWindows", "1", "--prepareThreads", "1", "--reduceThreads", "1")[0]).read()
+    assert a == d == e
     lst = str(scene["tmp"] / "glfs.txt")
     open(lst, "w").write(str(scene["tmp"] / "b64.glf.txt") + "\n")
     vcf = str(scene["tmp"] / "calls.vcf")

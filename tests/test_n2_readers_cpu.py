@@ -162,6 +162,96 @@ def test_get_reads_filter_branches(lib, tmp_path):
     assert two[1] == got[0]
 
 
+def _pairs_scene(rng, n_ref):
+    """Single reads, proper pairs, pairs with a far or foreign mate, mapped reads with an unmapped mate, flagged records."""
+    recs, k = [], 0
+    bases = lambda L: "".join(rng.choice(list("ACGT"), L))
+    for _ in range(900):
+        k += 1
+        name, pos, L = "q%04d" % k, int(rng.integers(3000, n_ref - 1000)), int(rng.integers(40, 130))
+        mapq = int(rng.choice([0, 10, 20, 30, 40, 60, 60, 60]))
+        kind = rng.random()
+        if kind < 0.35:
+            recs.append(mk(name, pos, flag=int(rng.choice([0, 16])), mapq=mapq, L=L, seq=bases(L)))
+        elif kind < 0.65:                                                     # proper pair, both mapped
+            p2, L2 = pos + int(rng.integers(0, 400)), int(rng.integers(40, 130))
+            recs.append(mk(name, pos, flag=99, mapq=mapq, L=L, seq=bases(L), mtid=0, mpos=p2))
+            recs.append(mk(name, p2, flag=147, mapq=int(rng.choice([20, 60])), L=L2, seq=bases(L2), mtid=0, mpos=pos))
+        elif kind < 0.72:                                                     # the mate is far away or on another chromosome
+            far = rng.random() < 0.5
+            recs.append(mk(name, pos, flag=97, mapq=mapq, L=L, seq=bases(L), mtid=0 if far else 1, mpos=pos + 50000 if far else 77))
+        elif kind < 0.90:                                                     # mapped read + unmapped mate placed at the same position
+            rev = int(rng.choice([0, 16]))
+            recs.append(mk(name, pos, flag=1 + 8 + 64 + rev, mapq=mapq, L=L, seq=bases(L), mtid=0, mpos=pos))
+            recs.append(mk(name, pos, flag=1 + 4 + 128 + int(rng.choice([0, 16])), mapq=0, L=L, cigar="", seq=bases(L), mtid=0, mpos=pos))
+        elif kind < 0.94:
+            recs.append(mk(name, pos, flag=int(rng.choice([1024, 512, 2048])), mapq=mapq, L=L, seq=bases(L)))
+        elif kind < 0.97:
+            recs.append(mk(name, pos, flag=1 + 32, mapq=mapq, L=L, seq=bases(L), mtid=0, mpos=-1))      # paired, mate "mapped", position unknown
+        else:
+            recs.append(mk(name, pos, mapq=mapq, L=150, cigar="60M30D90M", seq=bases(150)))
+    recs.sort(key=lambda r: r["pos"])                                         # stable: a pair at one position keeps its order
+    return recs
+
+
+@pytest.mark.parametrize("map_unmapped", [0, 1])
+def test_get_reads_against_the_python_restatement(lib, tmp_path, map_unmapped):
+    """Consecutive windows (overlapping, adjacent, far apart, left of maxInsert + 200, empty) over a mixed sample: every window's
+    outcome equals tests/_getreads_oracle.py — the thrown message, or the reads in mapping-quality order (ties as sets: their
+    order is std::sort's)."""
+    from tests import _getreads_oracle as go
+    rng = np.random.default_rng(77 + map_unmapped)
+    n_ref = 60000
+    recs = _pairs_scene(rng, n_ref)
+    path = str(tmp_path / "p.bam")
+    bw.write_bam(path, "@SQ\tSN:20\tLN:%d\n@SQ\tSN:21\tLN:1000\n" % n_ref, [("20", n_ref), ("21", 1000)], [(0, r) for r in recs])
+    windows, left = [(1500, 1620), (2100, 2230)], 3000                          # the first two: leftPos - 2200 wraps (nothing is fetched)
+    while left < n_ref - 2000:
+        windows.append((left, left + int(rng.integers(60, 200))))
+        left += int(rng.choice([0, 30, 150, 400, 900, 2500, 6000]))
+    flat = (C.c_int * (2 * len(windows)))(*[v for w in windows for v in w])
+    for max_reads, max_len, thr in ((10000, 500, 0.99), (10000, 120, 0.5), (12, 500, 0.99)):
+        prm = (C.c_int * 4)(max_reads, max_len, 20, map_unmapped)
+        got = call_json(lib.ddh_get_reads_json, path.encode(), b"", b"20", flat, len(windows), prm, thr, cap=1 << 26)
+        want = go.run_windows(recs, windows, max_reads=max_reads, max_read_length=max_len, map_unmapped=bool(map_unmapped), map_qual_threshold=thr)
+        assert len(got) == len(want)
+        n_ok = 0
+        for w, (g, e) in enumerate(zip(got, want)):
+            if isinstance(e, dict):
+                assert g == e, (w, windows[w])
+                continue
+            n_ok += 1
+            g = [(r[0], r[1], r[2], r[3], r[4], r[5], r[6]) for r in g["reads"]]
+            assert [x[2] for x in g] == pytest.approx([x[2] for x in e], rel=0, abs=0), (w, windows[w])
+            assert sorted(g) == sorted(e), (w, windows[w])
+        assert n_ok >= 5 and any(isinstance(e, dict) for e in want)
+
+
+def test_fetches_on_one_handle_match_fresh_ones(lib, tmp_path):
+    """BamFile::fetch keeps inflated blocks and, for ascending regions, resumes where the previous fetch found its first
+    overlapping record: a sequence of fetches on one handle returns what a fresh handle returns for each region."""
+    rng = np.random.default_rng(5)
+    recs = random_records(rng, 3000, 120000, ["g1"])
+    for r in recs[::7]:
+        r["cigar"], r["seq"], r["qual"] = "20M%dN20M" % int(rng.integers(1000, 40000)), "A" * 40, [30] * 40      # long spliced reads sit in high-level bins
+    path = str(tmp_path / "s.bam")
+    bw.write_bam(path, "@SQ\tSN:20\tLN:200000\n", [("20", 200000)], [(0, r) for r in recs], block_bytes=1500)
+    regions, beg = [], 0
+    while beg < 119000:
+        regions.append((beg, beg + int(rng.integers(1, 3000))))
+        beg += int(rng.integers(0, 2500))
+    regions += [(50000, 50100), (100, 900), (100, 900), (60000, 60001), (59990, 70000)]         # going back, repeating
+    flat = (C.c_int * (2 * len(regions)))(*[v for r in regions for v in r])
+    L = lib
+    L.ddh_bam_fetch_seq_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+    seq = call_json(L.ddh_bam_fetch_seq_json, path.encode(), b"20", flat, len(regions), cap=1 << 26)
+    ends = [r["pos"] + (bw.ref_len(bw.parse_cigar(r["cigar"])) if r["cigar"] else 1) for r in recs]
+    for (b, e), got in zip(regions, seq):
+        fresh = call_json(lib.ddh_bam_fetch_json, path.encode(), b"20", b, e)
+        assert got == [x["qname"] for x in fresh["records"]], (b, e)
+        assert got == [r["qname"] for r, en in zip(recs, ends) if en > b and r["pos"] < e], (b, e)
+
+
 def test_position_statistics_follow_the_cigar(lib, tmp_path):
     """Read::computePositionStatistics (Read.hpp:261-306): mean offset of the matched segments, e.g. 40M2D60M -> 60 * 2 / 100 = 1.2."""
     recs = [mk("del", 10000, cigar="40M2D60M"), mk("ins", 10001, cigar="30M5I65M"), mk("clip", 10002, cigar="10S90M"), mk("plain", 10003)]
