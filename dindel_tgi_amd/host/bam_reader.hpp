@@ -68,12 +68,17 @@ public:
     // bam_get_library: LB of the @RG line whose ID equals the record's RG tag; NULL if the tag or the library is missing
     const char *getLibrary(const BamRecord &b) const;
     // bam_fetch: every record of reference `tid` overlapping [beg, end), in file order.  The callback returns false to stop.
-    template <class F> void fetch(int tid, int beg, int end, F callback);
+    template <class F> void fetch(int tid, int beg, int end, F callback) { fetchImpl(tid, beg, end, callback, true); }
+    // The same traversal handing over records with the fixed fields and the CIGAR only (qname, seq, qualities, aux empty or
+    // stale); the callback calls complete(record) on those it wants whole.  Valid only inside the callback.
+    template <class F> void fetchCore(int tid, int beg, int end, F callback) { fetchImpl(tid, beg, end, callback, false); }
+    void complete(BamRecord &b) const { decodeRest(raw, b); }
     bool next(BamRecord &b);                             // sequential read at the current position (false at end of file)
     std::string fileName;
 private:
     // One record, undecoded: fetch() looks at tid / pos / CIGAR only and decodes the rest (name, bases, qualities, tags) of
     // the records it hands to the callback.
+    template <class F> void fetchImpl(int tid, int beg, int end, F callback, bool whole);
     bool nextRaw(std::vector<uint8_t> &d);
     static void decodeCore(const std::vector<uint8_t> &d, BamRecord &b);     // fixed fields + CIGAR
     static void decodeRest(const std::vector<uint8_t> &d, BamRecord &b);
@@ -95,7 +100,7 @@ private:
     std::vector<RefIndex> index;
 };
 
-template <class F> void BamFile::fetch(int tid, int beg, int end, F callback)
+template <class F> void BamFile::fetchImpl(int tid, int beg, int end, F callback, bool whole)
 {
     const std::vector<Chunk> chunks = chunksFor(tid, beg, end);
     const bool resumable = resume.valid && resume.tid == tid && beg >= resume.beg;
@@ -113,7 +118,7 @@ template <class F> void BamFile::fetch(int tid, int beg, int end, F callback)
             if (int(b.endPos()) > beg) {
                 if (!noted) { resume.tid = tid; resume.beg = beg; resume.voffset = here; resume.valid = true; noted = true; }
                 if (b.pos < end) {                                       // is_overlap
-                    decodeRest(raw, b);
+                    if (whole) decodeRest(raw, b);
                     if (!callback(b)) return;
                 }
             }

@@ -363,8 +363,34 @@ bool WindowLikelihoods::offHapHMQ(size_t h, size_t r) const { return blk_->offHa
 int WindowLikelihoods::numIndels(size_t h, size_t r) const { return blk_->numIndels[pair(h, r)]; }
 int WindowLikelihoods::indelCount(size_t h, size_t r) const
 {
-    if (!blk_->faster) return blk_->numIndels[pair(h, r)];
-    return int(get(h, r).indels.size());           // --faster: the map's size needs the walk over hpos
+    const BatchBlock &B = *blk_;
+    if (!B.faster) return B.numIndels[pair(h, r)];
+    if (!B.has_hpos) return int(get(h, r).indels.size());
+    // --faster: the size of the record's indel map needs the walk over hpos (rebuildAlignmentFaster), but not the record:
+    // the keys that walk would enter — an insertion run's recorded position, a deletion's first base — counted once each
+    const int r0 = B.win_read_off[w_];
+    const int64_t SL = int64_t(B.read_seq_off[B.win_read_off[w_ + 1]]) - B.read_seq_off[r0];
+    const int16_t *hp = B.hpos.p + B.hpos_off[w_] + int64_t(h) * SL + (B.read_seq_off[size_t(r0) + r] - B.read_seq_off[r0]);
+    const int L = int((*reads_)[r].size());
+    int keys[64], nk = 0, lhp = 1, b = 0;
+    bool spilled = false;
+    while (b < L && !spilled) {
+        const int c = hp[b];
+        int key = -1;
+        if (DD_HPOS_IS_INS(c)) {
+            while (b < L && DD_HPOS_IS_INS(hp[b])) b++;
+            key = (c != MLAlignment::INS) ? DD_HPOS_INS_POS(c) : lhp;
+        } else {
+            if (c >= 0) { lhp = c + 1; if (b < L - 1 && hp[b + 1] >= 0 && hp[b + 1] - c > 1) key = c + 1; }
+            b++;
+        }
+        if (key >= 0) {
+            bool seen = false;
+            for (int k = 0; k < nk; k++) if (keys[k] == key) seen = true;
+            if (!seen) { if (nk == 64) spilled = true; else keys[nk++] = key; }
+        }
+    }
+    return spilled ? int(get(h, r).indels.size()) : nk;
 }
 int WindowLikelihoods::numMismatch(size_t h, size_t r) const { return blk_->numMismatch[pair(h, r)]; }
 int WindowLikelihoods::nBQT(size_t h, size_t r) const { return blk_->nBQT[pair(h, r)]; }
@@ -407,6 +433,9 @@ bool WindowLikelihoods::hapIndelFilterCovered(size_t h, size_t r, int key) const
     const int s = varSlot(h, key, false);
     return s >= 0 && blk_->fcov[var_base(*blk_, w_, h, r) + s] != 0;
 }
+
+bool WindowLikelihoods::coveredAt(size_t h, size_t r, int slot) const { return slot >= 0 && blk_->vcov[var_base(*blk_, w_, h, r) + slot] != 0; }
+bool WindowLikelihoods::filterCoveredAt(size_t h, size_t r, int slot) const { return slot >= 0 && blk_->fcov[var_base(*blk_, w_, h, r) + slot] != 0; }
 
 MLAlignment WindowLikelihoods::get(size_t h, size_t r) const
 {

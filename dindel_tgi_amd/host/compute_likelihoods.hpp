@@ -63,6 +63,11 @@ public:
     bool hapIndelCovered(size_t h, size_t r, int key) const;
     bool hapSNPCovered(size_t h, size_t r, int key) const;
     bool hapIndelFilterCovered(size_t h, size_t r, int key) const;
+    // the same flags by slot, for loops over the reads of one (haplotype, variant): slot = varSlot(h, key, snp) once,
+    // then coveredAt / filterCoveredAt per read (slot < 0: false)
+    int varSlot(size_t h, int key, bool snp) const;
+    bool coveredAt(size_t h, size_t r, int slot) const;
+    bool filterCoveredAt(size_t h, size_t r, int slot) const;
     // the full record of one pair, built on demand (variant maps, align string, hpos).  If the batch was run without
     // alignments (setKeepAlignments(false)) the window is recomputed once through the engine and cached.
     MLAlignment get(size_t h, size_t r) const;
@@ -72,7 +77,6 @@ public:
 private:
     friend class LikelihoodEngine;
     int64_t pair(size_t h, size_t r) const;
-    int varSlot(size_t h, int key, bool snp) const;
     std::shared_ptr<const BatchBlock> blk_;
     mutable std::shared_ptr<const BatchBlock> full_;   // recomputed one-window block (no-alignment batches)
     int w_;

@@ -21,7 +21,7 @@
 //   --bamFile F --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
 //   [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
-//   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--reduceThreads N] [--device D] [--quiet]
+//   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D] [--quiet]
 //   [--timing]        one "timing:" line on stdout with the busy time of each stage
 //   [--prepareOnly]   stop after the prepare stage (no likelihoods, no calls: profiling the read selection on a GPU-less host)
 #include <atomic>
@@ -57,6 +57,8 @@ struct WindowTask {
 };
 struct Batch {
     long seq;                            // position in the file: batches are computed and written in this order
+    // A finished batch goes back to the reader and is filled again: its windows' read vectors (one string and one vector of
+    // base qualities per read) are overwritten in place instead of being freed by one thread and allocated anew by another.
     std::vector<WindowTask> tasks;
     std::vector<WindowJob> jobs;
     std::vector<size_t> jobOf;
@@ -90,6 +92,54 @@ public:
     void abort() { std::lock_guard<std::mutex> lk(m_); closed_ = true; q_.clear(); cv_.notify_all(); }
 private:
     std::mutex m_; std::condition_variable cv_; std::deque<BatchPtr> q_; size_t cap_; bool closed_;
+};
+
+// hand-over that restores file order: batches may arrive in any order, leave by sequence number; a batch more than `cap`
+// ahead of the next one to leave waits at the door (the one that is next never does, so the stages cannot lock up)
+class OrderedChannel {
+public:
+    explicit OrderedChannel(long cap) : cap_(cap), next_(0), closed_(false), aborted_(false) {}
+    bool push(BatchPtr &b)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        const long seq = b->seq;
+        cv_.wait(lk, [&] { return seq < next_ + cap_ || aborted_; });
+        if (aborted_) return false;
+        held_[seq] = std::move(b);
+        cv_.notify_all();
+        return true;
+    }
+    bool pop(BatchPtr &b)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return held_.find(next_) != held_.end() || closed_ || aborted_; });
+        std::map<long, BatchPtr>::iterator it = held_.find(next_);
+        if (aborted_ || it == held_.end()) return false;
+        b = std::move(it->second);
+        held_.erase(it);
+        next_++;
+        cv_.notify_all();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; cv_.notify_all(); }
+    void abort() { std::lock_guard<std::mutex> lk(m_); aborted_ = true; held_.clear(); cv_.notify_all(); }
+private:
+    std::mutex m_; std::condition_variable cv_; std::map<long, BatchPtr> held_; long cap_, next_; bool closed_, aborted_;
+};
+
+class BatchPool {
+public:
+    BatchPtr take()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (free_.empty()) return BatchPtr(new Batch);
+        BatchPtr b = std::move(free_.back());
+        free_.pop_back();
+        return b;
+    }
+    void give(BatchPtr &b) { std::lock_guard<std::mutex> lk(m_); free_.push_back(std::move(b)); }
+private:
+    std::mutex m_; std::vector<BatchPtr> free_;
 };
 
 double seconds_since(const std::chrono::steady_clock::time_point &t0)
@@ -134,8 +184,12 @@ int main(int argc, char **argv)
         const bool faster = has("faster"), oneBased = has("varFileIsOneBased"), prepareOnly = has("prepareOnly");
         unsigned hw = std::thread::hardware_concurrency();
         if (!hw) hw = 1;
-        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(8u, std::max(1u, hw / 4))))));
-        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(8u, std::max(1u, hw / 2))))));
+        // defaults measured on a 16-CPU share of an MI355X host (profiles/r02/n2_pipeline.md): per window the read selection and
+        // diploidGLF cost about the same CPU time, two engines keep the GPU busy while one of them packs
+        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
+        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
+        const int computeThreads = std::max(1, int(num("computeThreads", hw >= 8 ? 2.0 : 1.0)));
+        const int packThreads = int(num("packThreads", double(std::min(4u, std::max(1u, hw / 4)))));   // host threads of each engine's packing (0: the engine's default)
 
         LibraryCollection libraries;
         if (has("libFile")) {                    // the reference: --libFile switches mapUnmappedReads on (DInDel.cpp:4268-4272)
@@ -145,8 +199,7 @@ int main(int argc, char **argv)
         }
         { BamFile probe(opt["bamFile"]); }       // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens
         HaplotypeFixture fixture(opt["hapFile"]);
-        LikelihoodEngine engine(obs, int(num("device", 0)));
-        engine.setThrowOnPositiveLikelihood(false);
+        const int device = int(num("device", 0));
 
         const std::string glfFile = opt["outputFile"] + ".glf.txt";
         std::ofstream glfOutput(glfFile.c_str());
@@ -156,19 +209,17 @@ int main(int argc, char **argv)
         const double t_setup = seconds_since(t_start);
 
         long nWindows = 0, nSkipped = 0;
-        double t_prepare = 0.0, t_compute = 0.0, t_pack = 0.0, t_device = 0.0, t_unpack = 0.0, t_reduce = 0.0;
-        std::mutex fatal_m;
+        double t_reduce_work = 0.0, t_prepare = 0.0, t_compute = 0.0, t_pack = 0.0, t_device = 0.0, t_unpack = 0.0, t_reduce = 0.0;
+        std::mutex fatal_m, done_m;
+        std::condition_variable done_cv;
+        bool reduceDone = false;
         std::string fatal;
-        Channel toPrepare(size_t(prepareThreads) + 1), toCompute(2), toReduce(2);
-        std::mutex order_m;
-        std::condition_variable order_cv;
-        long nextToCompute = 0;                  // the batch the compute stage takes next
-        bool orderAborted = false;
+        BatchPool recycled;
+        Channel toPrepare(size_t(prepareThreads) + 1);
+        OrderedChannel toCompute(computeThreads + 1), toReduce(computeThreads + 1);
         auto fail = [&](const std::string &s) {
             { std::lock_guard<std::mutex> lk(fatal_m); if (fatal.empty()) fatal = s; }
             toPrepare.abort(); toCompute.abort(); toReduce.abort();
-            { std::lock_guard<std::mutex> lk(order_m); orderAborted = true; }
-            order_cv.notify_all();
         };
 
         // ---- prepare: whole batches side by side, handed on in file order ----
@@ -203,24 +254,26 @@ int main(int argc, char **argv)
                         fetcher.windowDone(T.skipped, T.fileLeftPos);                         // :1401-1408
                     }
                     t_prepare_of[size_t(pt)] += seconds_since(t0);
-                    std::unique_lock<std::mutex> lk(order_m);
-                    const long seq = b->seq;
-                    order_cv.wait(lk, [&] { return nextToCompute == seq || orderAborted; });
-                    if (orderAborted) break;
-                    const bool ok = toCompute.push(b);
-                    nextToCompute = seq + 1;
-                    lk.unlock();
-                    order_cv.notify_all();
-                    if (!ok) break;
+                    if (!toCompute.push(b)) break;
                 }
             } catch (std::string &s) { fail(s); }
             catch (std::exception &e) { fail(e.what()); }
         }));
 
-        // ---- compute: every prepared window of a batch in one call ----
-        std::thread computeThread([&]() {
+        // ---- compute: every prepared window of a batch in one call; --computeThreads engines take batches in turn, so that one
+        //      packs its batch (host) while the other's is on the GPU ----
+        std::vector<double> t_compute_of(size_t(computeThreads), 0.0), t_pack_of(size_t(computeThreads), 0.0), t_device_of(size_t(computeThreads), 0.0),
+            t_unpack_of(size_t(computeThreads), 0.0);
+        std::vector<std::thread> computeWorkers;
+        std::atomic<int> computeLeft(computeThreads);
+        for (int ct = 0; ct < computeThreads; ct++) computeWorkers.push_back(std::thread([&, ct]() {
             BatchPtr b;
             try {
+                LikelihoodEngine engine(obs, device);
+                engine.setThrowOnPositiveLikelihood(false);
+                // diploidGLF reads scalars and covered flags only; the --faster model's indel count (DInDel.cpp:3529) needs hpos
+                engine.setKeepAlignments(faster);
+                if (packThreads > 0) engine.setHostThreads(packThreads);
                 while (toCompute.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                     Batch &B = *b;
@@ -233,15 +286,20 @@ int main(int argc, char **argv)
                     }
                     if (!B.jobs.empty() && !prepareOnly) {
                         if (faster) engine.computeLikelihoodsFasterBatch(B.jobs); else engine.computeLikelihoodsBatch(B.jobs);
-                        t_pack += engine.lastPackSeconds; t_device += engine.lastDeviceSeconds; t_unpack += engine.lastUnpackSeconds;
+                        t_pack_of[size_t(ct)] += engine.lastPackSeconds; t_device_of[size_t(ct)] += engine.lastDeviceSeconds;
+                        t_unpack_of[size_t(ct)] += engine.lastUnpackSeconds;
                     }
-                    t_compute += seconds_since(t0);
+                    t_compute_of[size_t(ct)] += seconds_since(t0);
                     if (!toReduce.push(b)) break;
                 }
+                b.reset();
+                if (--computeLeft == 0) toReduce.close();
+                // the batches still being reduced hold views into this engine's result blocks: wait for the writer
+                std::unique_lock<std::mutex> lk(done_m);
+                done_cv.wait(lk, [&] { return reduceDone; });
             } catch (std::string &s) { fail(s); }
             catch (std::exception &e) { fail(e.what()); }
-            toReduce.close();
-        });
+        }));
 
         // ---- reduce: windows of a batch side by side, each into its own buffer; written out in window order ----
         std::thread reduceThread([&]() {
@@ -252,6 +310,7 @@ int main(int argc, char **argv)
                     Batch &B = *b;
                     std::atomic<size_t> next(0);
                     auto work = [&]() {
+                        const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
                         for (;;) {
                             const size_t i = next.fetch_add(1);
                             if (i >= B.tasks.size()) break;
@@ -274,6 +333,9 @@ int main(int argc, char **argv)
                             if (T.skipped) local.output(skippedWindowLine(local, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
                             T.lines = os.str();
                         }
+                        const double dt = seconds_since(w0);
+                        std::lock_guard<std::mutex> lk(fatal_m);
+                        t_reduce_work += dt;
                     };
                     std::vector<std::thread> pool;
                     const int nt = int(std::min<size_t>(size_t(reduceThreads), B.tasks.size()));
@@ -290,7 +352,9 @@ int main(int argc, char **argv)
                         nWindows++;
                     }
                     glfOutput.flush();
-                    b.reset();                                                    // drops the batch's views: its result block can be reused
+                    B.jobs.clear();                                               // drops the batch's views: its result block can be reused
+                    B.jobOf.clear();
+                    recycled.give(b);
                     t_reduce += seconds_since(t0);
                 }
             } catch (std::string &s) { fail(s); }
@@ -305,11 +369,14 @@ int main(int argc, char **argv)
             long seq = 0;
             std::string oldTid("-1");
             uint32_t oldLeftPos = 0;
-            BatchPtr batch(new Batch);
+            BatchPtr batch = recycled.take();
+            size_t nTasks = 0;                                                                // batch->tasks[nTasks...] are left-overs of an earlier use
             auto flush = [&]() {
                 batch->seq = seq++;
+                batch->tasks.resize(nTasks);
                 const bool ok = toPrepare.push(batch);
-                batch.reset(new Batch);
+                batch = recycled.take();
+                nTasks = 0;
                 return ok;
             };
             while (!vf.eof()) {
@@ -323,30 +390,35 @@ int main(int argc, char **argv)
                     break;
                 }
                 oldLeftPos = uint32_t(cand.leftPos);
-                batch->tasks.push_back(WindowTask());
-                WindowTask &T = batch->tasks.back();
+                if (nTasks == batch->tasks.size()) batch->tasks.push_back(WindowTask());
+                WindowTask &T = batch->tasks[nTasks++];
+                T.lines.clear();
                 T.candidates = cand; T.tid = cand.tid; T.pos = uint32_t(cand.centerPos);
                 T.fileLeftPos = T.leftPos = uint32_t(cand.leftPos); T.fileRightPos = T.rightPos = uint32_t(cand.rightPos);
                 T.haps = NULL; T.skipped = false; T.message = "ok";
                 T.index = ++index;
-                if (int(batch->tasks.size()) >= batchWindows && !flush()) break;
+                if (int(nTasks) >= batchWindows && !flush()) break;
             }
-            if (!batch->tasks.empty()) flush();
+            if (nTasks) flush();
         } catch (std::string &s) { fail(s); }
         toPrepare.close();
         for (size_t t = 0; t < prepareWorkers.size(); t++) prepareWorkers[t].join();
         for (size_t t = 0; t < t_prepare_of.size(); t++) t_prepare += t_prepare_of[t];
         toCompute.close();
-        computeThread.join();
+        // the reduce stage ends when every batch has come through; the compute workers are released after it
         reduceThread.join();
+        { std::lock_guard<std::mutex> lk(done_m); reduceDone = true; }
+        done_cv.notify_all();
+        for (size_t t = 0; t < computeWorkers.size(); t++) computeWorkers[t].join();
+        for (int t = 0; t < computeThreads; t++) { t_compute += t_compute_of[size_t(t)]; t_pack += t_pack_of[size_t(t)]; t_device += t_device_of[size_t(t)]; t_unpack += t_unpack_of[size_t(t)]; }
         glfOutput.close();
         if (!fatal.empty()) throw fatal;
         if (rc) return rc;
         if (!has("quiet")) std::cout << "windows: " << nWindows << " skipped: " << nSkipped << " -> " << glfFile << std::endl;
         if (has("timing")) {
             const double wall = seconds_since(t_start);
-            std::cout << "timing: wall=" << wall << " setup=" << t_setup << " prepare_threads=" << prepareThreads << " prepare=" << t_prepare << " compute=" << t_compute << " (pack=" << t_pack
-                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce=" << t_reduce << " windows_per_s=" << double(nWindows) / wall << std::endl;
+            std::cout << "timing: wall=" << wall << " setup=" << t_setup << " prepare_threads=" << prepareThreads << " prepare=" << t_prepare << " compute_threads=" << computeThreads << " compute=" << t_compute << " (pack=" << t_pack
+                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce_threads=" << reduceThreads << " reduce=" << t_reduce << " (work=" << t_reduce_work << " summed over the threads)" << " windows_per_s=" << double(nWindows) / wall << std::endl;
         }
     } catch (std::string &s) {
         std::cerr << "Exception: " << s << std::endl;

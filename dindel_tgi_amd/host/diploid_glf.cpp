@@ -1,5 +1,6 @@
 // diploid_glf.cpp — see diploid_glf.hpp.  Line references are to the reference's DInDel.cpp.
 #include "diploid_glf.hpp"
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 #include <set>
@@ -14,25 +15,31 @@ void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read
     filtered = std::vector<int>(haps.size(), 0);
     varCoverage.clear();
     typedef std::map<int, AlignedVariant>::const_iterator It;
-    std::map<PAV, std::vector<std::set<int> > > hVarCoverage;                               // :1940-1944
+    // per variant, per (haplotype, strand): the reads covering it (:1940-1944).  Reads are visited in ascending order, so the
+    // reference's set<int> is a plain ascending list here.
+    std::map<PAV, std::vector<std::vector<int> > > hVarCoverage;
+    std::vector<int> selReads, strandOf(reads.size(), 0);
+    for (size_t r = 0; r < reads.size(); r++) {                                              // :1982-1987
+        if (reads[r].isUnmapped()) { if (!reads[r].mateIsReverse()) strandOf[r] = 1; }
+        else { if (reads[r].isReverse()) strandOf[r] = 1; }
+    }
     for (int h = 0; h < numHaps; h++) {
-        std::set<int> selReads;                                                              // :1951-1955
+        selReads.clear();                                                                    // :1951-1955
         for (size_t r = 0; r < reads.size(); r++)
-            if (!liks.offHapHMQ(size_t(h), r) && liks.numIndels(size_t(h), r) == 0) selReads.insert(int(r));
+            if (!liks.offHapHMQ(size_t(h), r) && liks.numIndels(size_t(h), r) == 0) selReads.push_back(int(r));
         bool allCovered = true;
         for (It it = haps[size_t(h)].indels.begin(); it != haps[size_t(h)].indels.end(); ++it) {
             const AlignedVariant &av = it->second;
             const PAV pav(it->first, av);
-            if (hVarCoverage.find(pav) == hVarCoverage.end()) hVarCoverage[pav] = std::vector<std::set<int> >(haps.size() * 2);
+            std::map<PAV, std::vector<std::vector<int> > >::iterator cv = hVarCoverage.find(pav);
+            if (cv == hVarCoverage.end()) cv = hVarCoverage.insert(std::make_pair(pav, std::vector<std::vector<int> >(haps.size() * 2))).first;
             if (av.getType() == AlignedVariant::INS || av.getType() == AlignedVariant::DEL) {
                 bool covered = false;
-                for (std::set<int>::const_iterator rt = selReads.begin(); rt != selReads.end(); ++rt) {
-                    const int r = *rt;
-                    int strand = 0;                                                          // :1982-1987
-                    if (reads[size_t(r)].isUnmapped()) { if (!reads[size_t(r)].mateIsReverse()) strand = 1; }
-                    else { if (reads[size_t(r)].isReverse()) strand = 1; }
-                    if (liks.hapIndelFilterCovered(size_t(h), size_t(r), it->first)) {       // the device's test (:1989-2054)
-                        hVarCoverage[pav][size_t(h + strand * numHaps)].insert(r);
+                const int slot = liks.varSlot(size_t(h), it->first, false);
+                for (size_t k = 0; k < selReads.size(); k++) {
+                    const int r = selReads[k];
+                    if (liks.filterCoveredAt(size_t(h), size_t(r), slot)) {                  // the device's test (:1989-2054)
+                        cv->second[size_t(h + strandOf[size_t(r)] * numHaps)].push_back(r);
                         covered = true;
                     }
                 }
@@ -41,13 +48,17 @@ void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read
         }
         if (doFilter && !allCovered) filtered[size_t(h)] = 1;                                // :2068-2073
     }
-    for (std::map<PAV, std::vector<std::set<int> > >::const_iterator it = hVarCoverage.begin(); it != hVarCoverage.end(); ++it) {
-        std::set<int> rf, rr;                                                                // :2088-2097
+    std::vector<char> seenF(reads.size()), seenR(reads.size());
+    for (std::map<PAV, std::vector<std::vector<int> > >::const_iterator it = hVarCoverage.begin(); it != hVarCoverage.end(); ++it) {
+        std::fill(seenF.begin(), seenF.end(), 0);                                            // :2088-2097: the union over the haplotypes kept
+        std::fill(seenR.begin(), seenR.end(), 0);
+        int nf = 0, nr = 0;
         for (int h = 0; h < numHaps; h++) if (filtered[size_t(h)] != 1) {
-            rf.insert(it->second[size_t(h)].begin(), it->second[size_t(h)].end());
-            rr.insert(it->second[size_t(h + numHaps)].begin(), it->second[size_t(h + numHaps)].end());
+            const std::vector<int> &f = it->second[size_t(h)], &rv = it->second[size_t(h + numHaps)];
+            for (size_t k = 0; k < f.size(); k++) if (!seenF[size_t(f[k])]) { seenF[size_t(f[k])] = 1; nf++; }
+            for (size_t k = 0; k < rv.size(); k++) if (!seenR[size_t(rv[k])]) { seenR[size_t(rv[k])] = 1; nr++; }
         }
-        varCoverage[it->first] = VariantCoverage(int(rf.size()), int(rr.size()));
+        varCoverage[it->first] = VariantCoverage(nf, nr);
     }
 }
 
@@ -152,8 +163,9 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             variants[size_t(idx)] = pav;
         }
     }
-    std::set<int> readidx;
-    for (size_t r = 0; r < nr; r++) readidx.insert(int(r));
+    const size_t numReadIdx = nr;                                                            // readidx of the reference: every read, ascending
+    std::vector<double> mqOf(nr);                                                            // -10 log10(1 - mapQual), used thrice per read and variant position
+    for (size_t r = 0; r < nr; r++) mqOf[r] = -10 * log10(1.0 - reads[r].mapQual);
 
     std::vector<double> prior(nh * nh, 0.0), pairs_posterior(nh * nh, 0);                    // :3068-3075
     for (size_t h1 = 0; h1 < nh; h1++)
@@ -161,9 +173,17 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
 
     std::vector<int> max_indel_pair(2, -1), max_noindel_pair(2, -1);
     double max_ll_indel = -HUGE_VAL, max_ll_noindel = -HUGE_VAL;
+    // log(0.5) + addLogs(rl[r][h1], rl[r][h2]) per haplotype pair and read: the reference evaluates it here and again for every
+    // variant position (:3372-3376); the values are kept, the sums are redone in the reference's order each time
+    std::vector<long> pairSlot(nh * nh, -1);
+    long nPairs = 0;
+    for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) pairSlot[h1 * nh + h2] = nPairs++;
+    const bool keepTerms = size_t(nPairs) * nr <= (size_t(1) << 23);                          // at most 64 MB; beyond that they are recomputed
+    std::vector<double> pairTerm(keepTerms ? size_t(nPairs) * nr : 0), scratchTerm(keepTerms ? 0 : nr);
     for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3083-3114
         double ll = 0.0;
-        for (size_t r = 0; r < nr; r++) ll += log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
+        double *term = keepTerms ? &pairTerm[size_t(pairSlot[h1 * nh + h2]) * nr] : scratchTerm.data();
+        for (size_t r = 0; r < nr; r++) { term[r] = log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]); ll += term[r]; }
         pairs_posterior[h1 * nh + h2] = ll + prior[h1 * nh + h2];
         const double pp = pairs_posterior[h1 * nh + h2];
         if (pp > max_ll_indel && (hap_num_candidate_indels[h1] > 0 || hap_num_candidate_indels[h2] > 0)) { max_ll_indel = pp; max_indel_pair[0] = int(h1); max_indel_pair[1] = int(h2); }
@@ -193,11 +213,12 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
                 const size_t h = size_t(max_indel_pair[size_t(i)]);
                 It iter = haps[h].indels.find(it->first);
                 if (iter != haps[h].indels.end() && iter->second.isIndel()) {
+                    const int slot = liks.varSlot(h, it->first, false);
                     for (size_t r = 0; r < nr; r++) {
                         bool nft = false, nrt = false;
-                        if (liks.hapIndelCovered(h, r, it->first)) {                          // :3158-3159
+                        if (liks.coveredAt(h, r, slot)) {                                    // liks[h][r].hapIndelCovered[pos], :3158-3159
                             if (reads[r].onReverseStrand) nrt = true; else nft = true;
-                            const double mq = -10 * log10(1.0 - reads[r].mapQual);
+                            const double mq = mqOf[r];
                             msq += mq * mq;
                             n++;
                         }
@@ -238,20 +259,24 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
                 vc_r += varCoverage[PAV(it->first, avar)].nr;
             }
             double max_ll_altgeno = -HUGE_VAL;                                               // genotype quality (:3238-3265)
+            static const std::string refAllele("*REF");
+            std::vector<const std::string *> alleleOf(nh);                                   // each haplotype's allele at this position
+            for (size_t h = 0; h < nh; h++) {
+                It it2 = haps[h].indels.find(it->first);
+                alleleOf[h] = (it2 == haps[h].indels.end() || it2->second.isRef()) ? &refAllele : &it2->second.getString();
+            }
             for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {
                 if (!((h1 == hx1 && h2 == hx2) || (h2 == hx1 && h1 == hx2))) {
-                    std::set<std::string> alt_genotype;
-                    It it2 = haps[h1].indels.find(it->first);
-                    alt_genotype.insert((it2 == haps[h1].indels.end() || it2->second.isRef()) ? std::string("*REF") : it2->second.getString());
-                    it2 = haps[h2].indels.find(it->first);
-                    alt_genotype.insert((it2 == haps[h2].indels.end() || it2->second.isRef()) ? std::string("*REF") : it2->second.getString());
-                    if (alt_genotype != all_genotype && max_ll_altgeno < pairs_posterior[h1 * nh + h2]) max_ll_altgeno = pairs_posterior[h1 * nh + h2];
+                    // set<string>{x, y} != set<string>{a1, a2} of the reference
+                    const std::string &x = *alleleOf[h1], &y = *alleleOf[h2];
+                    const bool same = (x == a1 || x == a2) && (y == a1 || y == a2) && (a1 == x || a1 == y) && (a2 == x || a2 == y);
+                    if (!same && max_ll_altgeno < pairs_posterior[h1 * nh + h2]) max_ll_altgeno = pairs_posterior[h1 * nh + h2];
                 }
             }
             const double genoqual = -10.0 * (max_ll_altgeno - addLogs(max_ll_indel, max_ll_altgeno)) / log(10.0);
             DipMapCall c;
             c.index = index; c.tid = tid; c.leftPos = leftPos; c.rightPos = rightPos; c.candPos = candPos; c.realignedPos = it->first + int(leftPos);
-            c.was_candidate = was_candidate; c.qual = qual; c.nref_all = nref_all; c.num_reads = readidx.size(); c.msq = msq; c.numf = numf; c.numr = numr;
+            c.was_candidate = was_candidate; c.qual = qual; c.nref_all = nref_all; c.num_reads = numReadIdx; c.msq = msq; c.numf = numf; c.numr = numr;
             c.vc_f = vc_f; c.vc_r = vc_r; c.numUnmappedRealigned = numUnmappedRealigned; c.genotype = genotype; c.genoqual = genoqual;
             glfData.output(dipMapLine(glfData, c));
         }
@@ -264,7 +289,6 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             const AlignedVariant &avar = pt->second;
             if (candidateVariants.findVariant(avar.getStartHap() + int(leftPos), avar.getType(), avar.getString()) != NULL) { has_variants_in_window = 1; break; }
         }
-        const double log5 = log(0.5);
         int nf = 0, nrv = 0;
         const int pos = it->first;
         const int posIdx = posToPosIdx[pos];
@@ -272,6 +296,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         int n = 0;
         typedef std::set<int> IntGenotype;
         std::map<IntGenotype, double> genLiks;
+        std::map<std::pair<int, int>, double> pairPriorAt;
         double maxll = -HUGE_VAL;
         size_t hx1 = 0, hx2 = 0;
         for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3347-3389
@@ -279,12 +304,20 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             const int v1 = hapVar[h1 * size_t(numVarPos) + size_t(posIdx)], v2 = hapVar[h2 * size_t(numVarPos) + size_t(posIdx)];
             genotype.insert(v1);
             genotype.insert(v2);
-            const AlignedVariant av1 = v1 ? variants[size_t(v1)].second : AlignedVariant("*REF", -1);
-            const AlignedVariant av2 = v2 ? variants[size_t(v2)].second : AlignedVariant("*REF", -1);
-            const double logPriorPos = getPairPrior(av1, av2, int(leftPos), candidateVariants, params);
+            double logPriorPos;                                                              // a function of (v1, v2) alone at this position
+            std::map<std::pair<int, int>, double>::const_iterator known = pairPriorAt.find(std::make_pair(v1, v2));
+            if (known != pairPriorAt.end()) logPriorPos = known->second;
+            else {
+                const AlignedVariant av1 = v1 ? variants[size_t(v1)].second : AlignedVariant("*REF", -1);
+                const AlignedVariant av2 = v2 ? variants[size_t(v2)].second : AlignedVariant("*REF", -1);
+                logPriorPos = pairPriorAt[std::make_pair(v1, v2)] = getPairPrior(av1, av2, int(leftPos), candidateVariants, params);
+            }
             const double pr = prior[h1 * nh + h2] - logPriorPos;       // the site's prior taken out again: a likelihood
             double ll = pr;
-            for (size_t r = 0; r < nr; r++) ll += log5 + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
+            if (keepTerms) {
+                const double *term = &pairTerm[size_t(pairSlot[h1 * nh + h2]) * nr];
+                for (size_t r = 0; r < nr; r++) ll += term[r];
+            } else for (size_t r = 0; r < nr; r++) ll += log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
             std::map<IntGenotype, double>::iterator igit = genLiks.find(genotype);
             if (igit == genLiks.end()) genLiks[genotype] = ll; else genLiks[genotype] = addLogs(genLiks[genotype], ll);
             if (ll > maxll) { maxll = ll; hx1 = h1; hx2 = h2; }
@@ -295,9 +328,9 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         double allmsq = 0.0;                                                                 // :3492-3560
         int numMappedIndels = 0, nBQT = 0, nmmBQT = 0, nMMLeft = 0, nMMRight = 0, numOffBoth = 0;
         double mLogBQ = 0.0;
-        for (std::set<int>::const_iterator rt = readidx.begin(); rt != readidx.end(); ++rt) {
-            const size_t r = size_t(*rt);
-            const double mq = -10 * log10(1.0 - reads[r].mapQual);
+        std::vector<int> slotOf(nh, -2);                                                     // the position's slot in each haplotype's flag list, on first use
+        for (size_t r = 0; r < numReadIdx; r++) {
+            const double mq = mqOf[r];
             allmsq += (mq * mq);
             if (liks.offHap(hx1, r) && liks.offHap(hx2, r)) numOffBoth++;
             const size_t h = (liks.ll(hx1, r) >= liks.ll(hx2, r)) ? hx1 : hx2;                // the read's better haplotype of the pair
@@ -308,14 +341,18 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             mLogBQ += liks.mLogBQ(h, r);
             if (liks.nMMLeft(h, r) >= 2) nMMLeft++;
             if (liks.nMMRight(h, r) >= 2) nMMRight++;
-            It hit = haps[h].indels.find(pos);
-            if (hit != haps[h].indels.end()) {
-                if (hit->second.isIndel()) covered = liks.hapIndelCovered(h, r, pos);
-                else if (hit->second.isSNP()) covered = liks.hapSNPCovered(h, r, pos);
+            if (slotOf[h] == -2) {                                                           // :3536-3541
+                slotOf[h] = -1;
+                It hit = haps[h].indels.find(pos);
+                if (hit != haps[h].indels.end()) {
+                    if (hit->second.isIndel()) slotOf[h] = liks.varSlot(h, pos, false);       // liks[h][r].hapIndelCovered[pos]
+                    else if (hit->second.isSNP()) slotOf[h] = liks.varSlot(h, pos, true);    // liks[h][r].hapSNPCovered[pos]
+                }
             }
+            covered = liks.coveredAt(h, r, slotOf[h]);
             if (covered) {
                 if (reads[r].onReverseStrand) nrt = true; else nft = true;
-                const double mq2 = -10 * log10(1.0 - reads[r].mapQual);
+                const double mq2 = mqOf[r];
                 msq += mq2 * mq2;
                 n++;
             }
@@ -323,11 +360,12 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             if (nrt) nrv++;
         }
         if (n != 0) msq = sqrt(msq / double(n)); else msq = 0.0;
-        allmsq = (readidx.size() != 0) ? sqrt(allmsq / double(readidx.size())) : 0;
+        allmsq = (numReadIdx != 0) ? sqrt(allmsq / double(numReadIdx)) : 0;
         std::map<int, int> toVCFidx;                                                         // :3572-3595
         int nidx = 1;
         toVCFidx[0] = 0;
-        std::ostringstream oAlleles, oCovForward, oCovReverse;
+        static thread_local std::ostringstream oAlleles, oCovForward, oCovReverse, o;        // reused: see OutputData::Line::set
+        oAlleles.str(std::string()); oCovForward.str(std::string()); oCovReverse.str(std::string()); o.str(std::string());
         int first = 1;
         for (size_t h = 0; h < nh; h++) {
             const int v = hapVar[h * size_t(numVarPos) + size_t(posIdx)];
@@ -340,7 +378,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
                 first = 0;
             }
         }
-        std::ostringstream o;                                                                // :3600-3613
+        // :3600-3613
         first = 1;
         for (std::map<IntGenotype, double>::iterator git = genLiks.begin(); git != genLiks.end(); ++git) {
             const int a1 = toVCFidx[*(git->first.begin())], a2 = toVCFidx[*(git->first.rbegin())];
@@ -351,7 +389,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             DipPositionRow d;
             d.index = index; d.tid = tid; d.program = program; d.leftPos = leftPos; d.rightPos = rightPos; d.candPos = candPos; d.realignedPos = pos + int(leftPos);
             d.has_variants_in_window = has_variants_in_window; d.logZ = maxll; d.nBQT = nBQT; d.nmmBQT = nmmBQT; d.mLogBQ = mLogBQ; d.nMMLeft = nMMLeft;
-            d.nMMRight = nMMRight; d.nref_all = oAlleles.str(); d.num_reads = readidx.size(); d.msq = allmsq; d.numOffAll = numOffBoth; d.num_indel = numMappedIndels;
+            d.nMMRight = nMMRight; d.nref_all = oAlleles.str(); d.num_reads = numReadIdx; d.msq = allmsq; d.numOffAll = numOffBoth; d.num_indel = numMappedIndels;
             d.nf = nf; d.nr = nrv; d.var_coverage_forward = oCovForward.str(); d.var_coverage_reverse = oCovReverse.str(); d.glf = o.str();
             d.numUnmappedRealigned = numUnmappedRealigned;
             glfData.output(dipPositionLine(glfData, d));

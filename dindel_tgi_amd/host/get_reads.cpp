@@ -90,7 +90,7 @@ uint64_t hashName(const std::string &s)
 // qname -> the buffer indices carrying it, ascending (what the reference keeps in two hash_map<string, list<int>>, :1063-1072)
 class NameIndex {
 public:
-    NameIndex(const std::vector<Read> &reads) : reads_(reads)
+    NameIndex(const std::deque<Read> &reads) : reads_(reads)
     {
         size_t cap = 16;
         while (cap < 2 * reads.size()) cap <<= 1;
@@ -136,7 +136,7 @@ public:
         return n;
     }
 private:
-    const std::vector<Read> &reads_;
+    const std::deque<Read> &reads_;
     size_t mask_;
     std::vector<int> slot_, next_, tail_, count_;
     std::vector<uint64_t> hash_;
@@ -147,7 +147,13 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
 {
     const bool reset = resetReadBuffer;
     if (leftPos < oldLeftPos) throw std::string("Windows are not sorted!");                  // the reference exits (:899-902)
-    reads.clear();
+    // `reads` comes back holding the selection and nothing else, as after the reference's reads.clear() (:904); what it held
+    // on entry is overwritten in place, so a caller that hands the same vector in again (dindel_gpu recycles its batches) spares
+    // the allocator one string and one vector per read
+    struct Trim {
+        std::vector<Read> &v; size_t n;
+        ~Trim() { v.resize(n); }
+    } out = { reads, 0 };
     if (int(rightPos - leftPos) < 3 * params.minReadOverlap) throw std::string("Choose a larger width or a smaller minReadOverlap.");
     const int maxDev = int(libraries.getMaxInsertSize());
     int numUnknownLib = 0;
@@ -161,10 +167,17 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         readBuffer.clear();
         oldRightFetchReadPos = rightFetchReadPos;
     } else {
-        size_t keep = 0;                                                                     // :942-961
-        for (size_t r = 0; r < readBuffer.size(); r++)
-            if (!(uint32_t(readBuffer[r].bamPos) < leftMostReadPos)) { if (keep != r) std::swap(readBuffer[keep], readBuffer[r]); keep++; }
-        readBuffer.resize(keep);
+        size_t drop = 0;                                                                     // :942-961
+        while (drop < readBuffer.size() && uint32_t(readBuffer[drop].bamPos) < leftMostReadPos) drop++;
+        bool prefixOnly = true;                                                              // one sorted file: the reads to drop are the oldest ones
+        for (size_t r = drop; r < readBuffer.size() && prefixOnly; r++) if (uint32_t(readBuffer[r].bamPos) < leftMostReadPos) prefixOnly = false;
+        if (prefixOnly) readBuffer.erase(readBuffer.begin(), readBuffer.begin() + long(drop));
+        else {
+            size_t keep = 0;
+            for (size_t r = 0; r < readBuffer.size(); r++)
+                if (!(uint32_t(readBuffer[r].bamPos) < leftMostReadPos)) { if (keep != r) std::swap(readBuffer[keep], readBuffer[r]); keep++; }
+            readBuffer.resize(keep);
+        }
         if (leftMostReadPos < oldRightFetchReadPos) leftFetchReadPos = oldRightFetchReadPos;
     }
     int numReads = int(readBuffer.size());
@@ -173,11 +186,12 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
             BamFile &bam = *myBams[b];
             const int maxNumReads = int(params.maxReads * 100);
             const int pool = int(b);
-            bam.fetch(bam.getTID(tid), int(leftFetchReadPos), int(rightFetchReadPos), [&](const BamRecord &rec) -> bool {
+            bam.fetchCore(bam.getTID(tid), int(leftFetchReadPos), int(rightFetchReadPos), [&](BamRecord &rec) -> bool {
                 if (!((rec.flag & BAM_FDUP) || (rec.flag & BAM_FQCFAIL) || (rec.flag & 0x800))) {              // Read.hpp:392
                     // :998-1004: a read starting left of the fetched stretch was picked up by an earlier window; the reference
                     // builds it and drops it afterwards.  Here it is counted and its library looked up (what can throw), not built.
                     const bool wanted = uint32_t(rec.pos) >= leftFetchReadPos;
+                    if (wanted || (rec.flag & BAM_FPAIRED)) bam.complete(rec);      // name, bases, qualities; the RG tag of a paired read
                     try {
                         if (wanted) readBuffer.push_back(makeRead(rec, bam, libraries, pool));
                         else lookupLibrary(rec, bam, libraries, std::string());
@@ -276,20 +290,20 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
     std::sort(sel.begin(), sel.end(), byMapQualDescending);                                  // :1218
     for (size_t max = 0; max < params.maxReads && max < sel.size(); max++) {                 // :1219-1227
         if (sel[max].mapQual < minMapQual) break;
-        reads.push_back(readBuffer[sel[max].idx]);
-        Read &rd = reads.back();
+        if (out.n < reads.size()) reads[out.n] = readBuffer[sel[max].idx]; else reads.push_back(readBuffer[sel[max].idx]);
+        Read &rd = reads[out.n++];
         rd.mapQual = sel[max].mapQual; rd.matePos = sel[max].matePos; rd.mateLen = sel[max].mateLen;
         if (sel[max].flip) { rd.reverseSeq(); rd.complementSeq(); }
         if (rd.matePos == -1 && rd.isPaired() && !rd.mateIsUnmapped()) { nMateposError++; rd.matePos = int32_t(rd.pos); }
         if (rd.isUnmapped()) nUnmapped++;
     }
     if (!params.quiet)
-        std::cout << "Number of reads: " << reads.size() << " out of " << oldNumReads << " # unmapped reads: " << nUnmapped << " numReadsUnknownLib: " << numUnknownLib
+        std::cout << "Number of reads: " << out.n << " out of " << oldNumReads << " # unmapped reads: " << nUnmapped << " numReadsUnknownLib: " << numUnknownLib
                   << " numChrMismatch: " << numTIDmismatch << " numMappedWithoutMate: " << numOrphan << " numUnmappedWithoutMate: " << numOrphanUnmapped << std::endl;
     if (nMateposError) std::cerr << "The mate position of " << nMateposError << " reads was recorded as -1 in the BAM file" << std::endl;
     (void)numInRegion;
-    if (reads.size() < 2) throw std::string("too_few_reads");                                // :1256-1260
-    else if (reads.size() >= params.maxReads) throw std::string("above_read_count_threshold");
+    if (out.n < 2) throw std::string("too_few_reads");                                       // :1256-1260
+    else if (out.n >= params.maxReads) throw std::string("above_read_count_threshold");
 }
 
 } // namespace dindel

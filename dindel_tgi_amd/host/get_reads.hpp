@@ -5,6 +5,7 @@
 //                                                                     sort by mapping quality, maxReads cap
 #ifndef DINDEL_GET_READS_HPP
 #define DINDEL_GET_READS_HPP
+#include <deque>
 #include <string>
 #include <vector>
 #include "bam_reader.hpp"
@@ -41,7 +42,7 @@ private:
     std::vector<BamFile *> &myBams;
     const LibraryCollection &libraries;
     ReadSelectionParameters params;
-    std::vector<Read> readBuffer;
+    std::deque<Read> readBuffer;         // reads leave at the front (the file is sorted) and arrive at the back
     uint32_t oldLeftPos, oldRightFetchReadPos;
     bool resetReadBuffer;
 };

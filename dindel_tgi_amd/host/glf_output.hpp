@@ -12,6 +12,7 @@
 #ifndef DINDEL_GLF_OUTPUT_HPP
 #define DINDEL_GLF_OUTPUT_HPP
 #include <cstdint>
+#include <cstdio>
 #include <map>
 #include <ostream>
 #include <sstream>
@@ -47,15 +48,32 @@ public:
             if (it == labelToColumnPtr->end()) throw std::string("Column label ").append(columnLabel).append(" not found!");
             return lineData[size_t(it->second)];
         }
+        // A cell holds what `stringstream << x` gives with default formatting (the reference makes one stringstream per cell,
+        // :82-84).  The common types are formatted directly — constructing a stream copies the global locale, whose reference
+        // count every reducing thread would be hammering ~30 times per line: integers as decimal digits, doubles as "%.6g"
+        // (what num_put does for the default float format and precision), strings as they are.
         template <class T> Line &set(const std::string &columnLabel, T x)
         {
-            std::map<std::string, int>::const_iterator it = labelToColumnPtr->find(columnLabel);
-            if (it == labelToColumnPtr->end()) throw std::string("Column label ").append(columnLabel).append(" not found!");
-            std::stringstream os;                       // default formatting, like the reference (:82-84)
+            static thread_local std::ostringstream os;
+            os.str(std::string());
+            os.clear();
             os << x;
-            lineData[size_t(it->second)] = os.str();
+            cell(columnLabel) = os.str();
             return *this;
         }
+        Line &set(const std::string &columnLabel, double x)
+        {
+            char buf[64];
+            snprintf(buf, sizeof(buf), "%.6g", x);
+            cell(columnLabel) = buf;
+            return *this;
+        }
+        Line &set(const std::string &columnLabel, int x) { cell(columnLabel) = std::to_string(x); return *this; }
+        Line &set(const std::string &columnLabel, unsigned x) { cell(columnLabel) = std::to_string(x); return *this; }
+        Line &set(const std::string &columnLabel, long x) { cell(columnLabel) = std::to_string(x); return *this; }
+        Line &set(const std::string &columnLabel, unsigned long x) { cell(columnLabel) = std::to_string(x); return *this; }
+        Line &set(const std::string &columnLabel, const std::string &x) { cell(columnLabel) = x; return *this; }
+        Line &set(const std::string &columnLabel, const char *x) { cell(columnLabel) = x; return *this; }
         std::string toString() const
         {
             std::string s;
@@ -64,6 +82,12 @@ public:
         }
         std::vector<std::string> lineData;
     private:
+        std::string &cell(const std::string &columnLabel)
+        {
+            std::map<std::string, int>::const_iterator it = labelToColumnPtr->find(columnLabel);
+            if (it == labelToColumnPtr->end()) throw std::string("Column label ").append(columnLabel).append(" not found!");
+            return lineData[size_t(it->second)];
+        }
         const std::map<std::string, int> *labelToColumnPtr;
     };
 
@@ -141,8 +165,8 @@ struct DipMapCall {
 };
 inline OutputData::Line dipMapLine(const OutputData &glfData, const DipMapCall &c)
 {
-    std::ostringstream glfs;
-    glfs << c.genotype << ":" << c.genoqual;                        // :3270
+    char genoqual[64];
+    snprintf(genoqual, sizeof(genoqual), "%.6g", c.genoqual);       // glfs << genotype << ":" << genoqual, :3270
     OutputData::Line line(glfData);
     line.set("msg", "ok");
     line.set("index", c.index);
@@ -163,7 +187,7 @@ inline OutputData::Line dipMapLine(const OutputData &glfData, const DipMapCall &
     line.set("var_coverage_forward", c.vc_f);
     line.set("var_coverage_reverse", c.vc_r);
     line.set("num_unmapped_realigned", c.numUnmappedRealigned);
-    line.set("glf", glfs.str());
+    line.set("glf", c.genotype + ":" + genoqual);
     return line;
 }
 

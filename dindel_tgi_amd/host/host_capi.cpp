@@ -389,6 +389,7 @@ int ddh_batch_json(int W, const int *n_haps, const int *n_reads, const char *hap
                                         V.nBQT(h, r) != m.nBQT || V.nmmBQT(h, r) != m.nmmBQT || V.nMMLeft(h, r) != m.nMMLeft || V.nMMRight(h, r) != m.nMMRight))
                             mismatch++;
                         if (!faster && V.numIndels(h, r) != int(m.indels.size())) mismatch++;      // what DInDel.cpp:3529 reads
+                        if (V.indelCount(h, r) != int(m.indels.size())) mismatch++;                // the view's shortcut to the same number
                         std::ostringstream a, b;
                         json_ml(a, m);
                         json_ml(b, V.get(h, r));
@@ -498,6 +499,17 @@ int ddh_format_double(double x, char *out, int cap)
     od("v");
     OutputData::Line line(od);
     line.set("v", x);
+    std::stringstream ref;                          // what the reference's Line::set does (OutputData.hpp:82-84)
+    ref << x;
+    if (ref.str() != line.get("v")) return emit(std::string("MISMATCH ") + line.get("v") + " vs " + ref.str(), out, cap);
+    const long asLong = long(x);
+    const unsigned asUnsigned = unsigned(asLong);
+    std::stringstream r1, r2, r3, r4;
+    r1 << asLong; r2 << asUnsigned; r3 << size_t(asUnsigned); r4 << int(asLong);
+    OutputData::Line l2(od);
+    if (l2.set("v", asLong).get("v") != r1.str() || l2.set("v", asUnsigned).get("v") != r2.str() || l2.set("v", size_t(asUnsigned)).get("v") != r3.str() ||
+        l2.set("v", int(asLong)).get("v") != r4.str())
+        return emit("MISMATCH integers", out, cap);
     return emit(line.get("v"), out, cap);
 }
 
@@ -579,6 +591,43 @@ int ddh_bam_fetch_seq_json(const char *path, const char *tid, const int *reg, in
             bool first = true;
             bam.fetch(t, reg[2 * k], reg[2 * k + 1], [&](const BamRecord &b) -> bool { os << (first ? "" : ",") << "\"" << b.qname << "\""; first = false; return true; });
             os << "]";
+        }
+        os << "]";
+        return emit(os.str(), out, cap);
+    } catch (std::string &e) {
+        return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// the haplotype fixture as the driver sees it: for the windows asked for, [index, leftPos, rightPos, [[seq, [[kind, key, string, startHap,
+// endHap, startRead, endRead, leftFlankHap, rightFlankHap, leftFlankRead, rightFlankRead], ...]], ...]] (null: no such window)
+int ddh_fixture_json(const char *path, const int *indices, int n, char *out, int cap)
+{
+    try {
+        HaplotypeFixture fx(path);
+        std::ostringstream os;
+        os << "[";
+        for (int k = 0; k < n; k++) {
+            const WindowHaplotypes *w = fx.find(indices[k]);
+            os << (k ? "," : "");
+            if (!w) { os << "null"; continue; }
+            os << "[" << w->index << "," << w->leftPos << "," << w->rightPos << ",[";
+            for (size_t h = 0; h < w->haps.size(); h++) {
+                os << (h ? "," : "") << "[\"" << w->haps[h].seq << "\",[";
+                bool first = true;
+                for (int pass = 0; pass < 2; pass++) {
+                    const std::map<int, AlignedVariant> &m = pass ? w->haps[h].snps : w->haps[h].indels;
+                    for (std::map<int, AlignedVariant>::const_iterator it = m.begin(); it != m.end(); ++it) {
+                        const AlignedVariant &v = it->second;
+                        os << (first ? "" : ",") << "[\"" << (pass ? "S" : "I") << "\"," << it->first << ",\"" << v.getString() << "\"," << v.getStartHap() << "," << v.getEndHap()
+                           << "," << v.getStartRead() << "," << v.getEndRead() << "," << v.getLeftFlankHap() << "," << v.getRightFlankHap() << "," << v.getLeftFlankRead() << ","
+                           << v.getRightFlankRead() << "]";
+                        first = false;
+                    }
+                }
+                os << "]]";
+            }
+            os << "]]";
         }
         os << "]";
         return emit(os.str(), out, cap);

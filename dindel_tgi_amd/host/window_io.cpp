@@ -1,6 +1,10 @@
 // window_io.cpp — see window_io.hpp.
 #include "window_io.hpp"
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <thread>
 #include <cmath>
 #include <iostream>
 #include <sstream>
@@ -148,23 +152,25 @@ double LibraryCollection::getMaxInsertSize() const
     return max;
 }
 
-HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
+namespace {
+// the records of one stretch of the fixture file (whole windows: the stretch starts at a W line or at the head of the file)
+void parseFixtureStretch(const char *p, const char *end, int lineNo, const std::string &fileName, std::vector<WindowHaplotypes> &out)
 {
-    std::ifstream fin(fileName.c_str());
-    if (!fin.is_open()) throw std::string("Cannot open haplotype file ").append(fileName);
-    std::string line;
     WindowHaplotypes *cur = NULL;
-    int lineNo = 0;
     std::vector<std::pair<const char *, size_t> > tok;                 // the line's blank-separated fields
-    while (std::getline(fin, line)) {
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
+        const char *le = nl ? nl : end;
         lineNo++;
-        if (line.empty() || line[0] == '#') continue;
+        const char *q = p;
+        p = nl ? nl + 1 : end;
+        if (q == le || *q == '#') continue;
         tok.clear();
-        for (size_t i = 0; i < line.size();) {
-            while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) i++;
-            const size_t st = i;
-            while (i < line.size() && !(line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) i++;
-            if (i > st) tok.push_back(std::make_pair(line.data() + st, i - st));
+        while (q < le) {
+            while (q < le && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+            const char *st = q;
+            while (q < le && !(*q == ' ' || *q == '\t' || *q == '\r')) q++;
+            if (q > st) tok.push_back(std::make_pair(st, size_t(q - st)));
         }
         if (tok.empty()) continue;
         auto bad = [&](const char *what) {
@@ -175,9 +181,9 @@ HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
         auto integer = [&](size_t k, const char *what) -> long {      // field k as a whole decimal number
             if (k >= tok.size()) throw bad(what);
             const std::string t(tok[k].first, tok[k].second);
-            char *end = NULL;
-            const long v = strtol(t.c_str(), &end, 10);
-            if (end == t.c_str() || *end) throw bad(what);
+            char *stop = NULL;
+            const long v = strtol(t.c_str(), &stop, 10);
+            if (stop == t.c_str() || *stop) throw bad(what);
             return v;
         };
         const std::string tag(tok[0].first, tok[0].second);
@@ -185,7 +191,8 @@ HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
             WindowHaplotypes w;
             w.index = int(integer(1, "Cannot read window record"));
             w.leftPos = uint32_t(integer(2, "Cannot read window record")); w.rightPos = uint32_t(integer(3, "Cannot read window record"));
-            cur = &(windows[w.index] = w);
+            out.push_back(w);
+            cur = &out.back();
         } else if (tag == "H") {
             if (!cur || tok.size() < 2) throw bad("Cannot read haplotype record");
             cur->haps.push_back(Haplotype(std::string(tok[1].first, tok[1].second)));
@@ -203,6 +210,55 @@ HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
             else throw bad("Variant record must say I or S");
         } else throw bad("Unknown record");
     }
+}
+}
+
+HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
+{
+    std::string text;
+    {
+        std::ifstream fin(fileName.c_str(), std::ios::binary);
+        if (!fin.is_open()) throw std::string("Cannot open haplotype file ").append(fileName);
+        std::ostringstream all;
+        all << fin.rdbuf();
+        text = all.str();
+    }
+    // cut at W lines into one stretch per worker; every stretch is parsed on its own and the windows are merged in file order
+    // (a later record of the same index replaces an earlier one, as a sequential read would)
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t workers = text.size() < (1u << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    std::vector<size_t> cut(1, 0);
+    for (size_t k = 1; k < workers; k++) {
+        size_t at = text.size() / workers * k;
+        for (;;) {
+            at = text.find("\nW", at);
+            if (at == std::string::npos) break;
+            if (at + 2 < text.size() && (text[at + 2] == ' ' || text[at + 2] == '\t')) { at++; break; }
+            at++;
+        }
+        if (at != std::string::npos && at > cut.back()) cut.push_back(at);
+    }
+    cut.push_back(text.size());
+    const size_t n = cut.size() - 1;
+    std::vector<std::vector<WindowHaplotypes> > parts(n);
+    std::vector<std::string> errors(n);
+    std::vector<int> lineBase(n, 0);
+    for (size_t k = 1; k < n; k++) lineBase[k] = lineBase[k - 1] + int(std::count(text.begin() + long(cut[k - 1]), text.begin() + long(cut[k]), '\n'));
+    std::vector<std::thread> pool;
+    auto work = [&](size_t k) {
+        try { parseFixtureStretch(text.data() + cut[k], text.data() + cut[k + 1], lineBase[k], fileName, parts[k]); }
+        catch (std::string &e) { errors[k] = e; }
+    };
+    for (size_t k = 1; k < n; k++) pool.push_back(std::thread(work, k));
+    work(0);
+    for (size_t k = 0; k < pool.size(); k++) pool[k].join();
+    for (size_t k = 0; k < n; k++) if (!errors[k].empty()) throw errors[k];                  // the first one in file order
+    for (size_t k = 0; k < n; k++)
+        for (size_t i = 0; i < parts[k].size(); i++) {
+            WindowHaplotypes &slot = windows[parts[k][i].index];
+            slot.index = parts[k][i].index; slot.leftPos = parts[k][i].leftPos; slot.rightPos = parts[k][i].rightPos;
+            slot.haps.swap(parts[k][i].haps);
+        }
 }
 
 const WindowHaplotypes *HaplotypeFixture::find(int index) const

@@ -37,6 +37,9 @@ def test_glf_cells_print_like_default_ostream():
     rng = np.random.default_rng(5)
     for x in np.concatenate([rng.normal(0, 50, 200), 10.0 ** rng.uniform(-12, 12, 200)]):
         assert fmt(float(x)) == "%g" % x
+    # the cells are formatted without a stream per cell; the hook reports a MISMATCH if that differs from `stringstream << x`
+    for x in [float("-inf"), -float("nan"), -0.0, 5e-324, 1e-310, 1.7976931348623157e308, 999999.5, 9999995.0, 0.1 + 0.2, -123456789.0, 2147483647.0, -2147483648.0, 4294967295.0]:
+        assert not fmt(x).startswith("MISMATCH"), (x, fmt(x))
 
 
 def test_glf_table_header_rows_and_na_defaults(tmp_path):

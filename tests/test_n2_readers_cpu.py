@@ -263,3 +263,50 @@ def test_position_statistics_follow_the_cigar(lib, tmp_path):
     assert reads["del"][7] == pytest.approx(10000 + 1.2) and reads["plain"][7] == 10003.0
     assert reads["ins"][7] == pytest.approx(10001 + 65 * (30 - 30) / 95.0)                    # insertions do not advance the position
     assert reads["clip"][7] == pytest.approx(10002 + 90 * 10 / 90.0)                           # a soft clip does
+
+
+def test_haplotype_fixture_file_large_and_broken(lib, tmp_path):
+    """The haplotype file stands in for getHaplotypes' output; files above 1 MB are parsed in stretches by several workers.  Every
+    window comes out as written (a repeated index: the later record wins), and a broken line is reported with its line number."""
+    rng = np.random.default_rng(8)
+    lines, want = ["# made by the test"], {}
+    for w in [5, 1, 9] + list(range(10, 1500)) + [9]:                     # out of order, and 9 twice
+        left = int(rng.integers(1000, 100000))
+        lines.append("W %d %d %d" % (w, left, left + 120))
+        haps = []
+        for h in range(int(rng.integers(1, 9))):
+            seq = "".join(rng.choice(list("ACGT"), int(rng.integers(80, 160))))
+            lines.append("H " + seq)
+            vs = {}
+            for _ in range(int(rng.integers(0, 5))):
+                kind, key = str(rng.choice(["I", "S"])), int(rng.integers(0, 100))
+                f = [int(x) for x in rng.integers(-1, 120, 8)]
+                s = str(rng.choice(["*REF", "+AC", "-T", "A=>G"]))
+                lines.append(("V %s %d %s " % (kind, key, s) + " ".join(map(str, f))) if rng.random() < 0.8 else ("V\t%s  %d %s\t" % (kind, key, s) + "  ".join(map(str, f)) + " "))
+                vs[(kind, key)] = [kind, key, s] + f                      # the same (kind, key) again replaces the entry
+            haps.append([seq, [vs[k] for k in sorted(vs, key=lambda k: (k[0] != "I", k[1]))]])
+        if rng.random() < 0.05:
+            lines.append("")
+        want[w] = [w, left, left + 120, haps]
+    text = "\n".join(lines) + "\n"
+    assert len(text) > (1 << 20)
+    path = str(tmp_path / "haps.txt")
+    open(path, "w").write(text)
+    lib.ddh_fixture_json.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+    ask = sorted(want) + [0, 4000]
+    got = call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * len(ask))(*ask), len(ask), cap=1 << 27)
+    assert got[-2:] == [None, None]
+    for w, g in zip(ask[:-2], got[:-2]):
+        assert g == want[w], w
+    # a broken record far into the file: the message names the line
+    bad_at = len(lines) - 40
+    while not lines[bad_at].startswith("V"):
+        bad_at -= 1
+    broken = list(lines)
+    broken[bad_at] = broken[bad_at].rsplit(None, 1)[0] + " x7"
+    open(path, "w").write("\n".join(broken) + "\n")
+    got = call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1)
+    assert got == {"throw": "Cannot read variant record in line %d of %s" % (bad_at + 1, path)}
+    open(path, "w").write("H ACGT\n")
+    assert call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot read haplotype record in line 1 of %s" % path}
+    assert call_json(lib.ddh_fixture_json, str(tmp_path / "nope").encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot open haplotype file %s" % (tmp_path / "nope")}

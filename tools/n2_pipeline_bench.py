@@ -25,6 +25,8 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--dir", default="/tmp/n2bench")
 ap.add_argument("--faster", action="store_true")
 ap.add_argument("--keep", action="store_true", help="reuse the files of an earlier run with the same parameters")
+ap.add_argument("--sweep", action="store_true", help="run a list of batch sizes / thread counts instead of one configuration")
+ap.add_argument("--extra", default="", help="further driver options, blank-separated")
 args = ap.parse_args()
 os.makedirs(args.dir, exist_ok=True)
 bam, vf, hf = [os.path.join(args.dir, n) for n in ("reads.bam", "windows.txt", "haps.txt")]
@@ -96,18 +98,23 @@ try:
     env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
 except ImportError:
     pass
-cmd = [os.path.join(host, "dindel_gpu"), "--bamFile", bam, "--varFile", vf, "--hapFile", hf, "--outputFile", os.path.join(args.dir, "out"),
-       "--batchWindows", str(args.batch), "--timing"] + (["--faster"] if args.faster else [])
-for rep in range(2):
-    t0 = time.time()
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True)
-    dt = time.time() - t0
-    if out.returncode != 0:
-        print(out.stderr[-2000:])
-        sys.exit(1)
-    rows = open(os.path.join(args.dir, "out.glf.txt")).read().split("\n")
-    calls = sum(1 for l in rows if " dip.map " in l)
-    skipped = sum(1 for l in rows[1:] if l and not l.startswith("ok "))
-    timing = [l for l in out.stdout.split("\n") if l.startswith("timing:")]
-    print(json.dumps(dict(rep=rep, windows=args.windows, batch=args.batch, faster=args.faster, seconds=round(dt, 3), windows_per_s=round(args.windows / dt, 1),
-                          dip_map_lines=calls, skipped=skipped, driver=timing[-1] if timing else None)), flush=True)
+base = [os.path.join(host, "dindel_gpu"), "--bamFile", bam, "--varFile", vf, "--hapFile", hf, "--outputFile", os.path.join(args.dir, "out"), "--timing"]
+if args.sweep:
+    configs = [["--batchWindows", str(b), "--computeThreads", str(c), "--prepareThreads", str(p), "--reduceThreads", str(r), "--packThreads", str(k)] + f
+               for f in ([], ["--faster"]) for (b, c, p, r, k) in ((256, 1, 8, 4, 0), (256, 1, 6, 6, 4), (256, 2, 6, 6, 4), (256, 1, 8, 8, 4), (512, 1, 8, 8, 4))]
+else:
+    configs = [["--batchWindows", str(args.batch)] + (["--faster"] if args.faster else []) + args.extra.split()]
+for cfg in configs:
+    for rep in range(2):
+        t0 = time.time()
+        out = subprocess.run(base + cfg, env=env, capture_output=True, text=True)
+        dt = time.time() - t0
+        if out.returncode != 0:
+            print(out.stderr[-2000:])
+            sys.exit(1)
+        rows = open(os.path.join(args.dir, "out.glf.txt")).read().split("\n")
+        calls = sum(1 for l in rows if " dip.map " in l)
+        skipped = sum(1 for l in rows[1:] if l and not l.startswith("ok "))
+        timing = [l for l in out.stdout.split("\n") if l.startswith("timing:")]
+        print(json.dumps(dict(rep=rep, windows=args.windows, options=" ".join(cfg), seconds=round(dt, 3), windows_per_s=round(args.windows / dt, 1),
+                              dip_map_lines=calls, skipped=skipped, driver=timing[-1] if timing else None)), flush=True)
