@@ -117,6 +117,83 @@ bool BgzfReader::read(void *dst, size_t n)
     return true;
 }
 
+// ---------------- BGZF output ----------------
+void BgzfWriter::open(const std::string &path)
+{
+    f = fopen(path.c_str(), "wb");
+    if (!f) throw std::string("Cannot open bamfile ").append(path).append(" for writing!");
+    pending.clear();
+}
+
+void BgzfWriter::flushBlock()
+{
+    const size_t n = pending.size();                       // may be 0: the end-of-file marker
+    std::vector<uint8_t> comp(compressBound(uLong(n)) + 64);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::string("zlib: deflateInit2 failed");
+    zs.next_in = n ? pending.data() : NULL; zs.avail_in = uInt(n);
+    zs.next_out = comp.data(); zs.avail_out = uInt(comp.size());
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = comp.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen + 26 > 65536) throw std::string("zlib: deflate failed on a BGZF block");
+    const uint32_t bsize = uint32_t(clen + 25);           // total block size - 1
+    const uint32_t crc = uint32_t(crc32(crc32(0L, Z_NULL, 0), n ? pending.data() : NULL, uInt(n)));
+    uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, uint8_t(bsize & 255), uint8_t(bsize >> 8)};
+    uint8_t tail[8] = {uint8_t(crc), uint8_t(crc >> 8), uint8_t(crc >> 16), uint8_t(crc >> 24), uint8_t(n), uint8_t(n >> 8), uint8_t(n >> 16), uint8_t(n >> 24)};
+    if (fwrite(hdr, 1, 18, f) != 18 || fwrite(comp.data(), 1, clen, f) != clen || fwrite(tail, 1, 8, f) != 8) throw std::string("Error writing BGZF block.");
+    pending.clear();
+}
+
+void BgzfWriter::write(const void *src, size_t n)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    const size_t kBlock = 0xff00;
+    while (n > 0) {
+        const size_t take = std::min(n, kBlock - pending.size());
+        pending.insert(pending.end(), p, p + take);
+        p += take; n -= take;
+        if (pending.size() == kBlock) flushBlock();
+    }
+}
+
+void BgzfWriter::close()
+{
+    if (!f) return;
+    if (!pending.empty()) flushBlock();
+    flushBlock();                                          // the empty end-of-file block
+    FILE *g = f;
+    f = NULL;
+    if (fclose(g) != 0) throw std::string("Error closing BGZF file.");
+}
+
+BamWriter::BamWriter(const std::string &path, const BamFile &like)
+{
+    out.open(path);
+    uint8_t w[4];
+    auto put32 = [&](uint32_t v) { w[0] = uint8_t(v); w[1] = uint8_t(v >> 8); w[2] = uint8_t(v >> 16); w[3] = uint8_t(v >> 24); out.write(w, 4); };
+    out.write("BAM\1", 4);
+    const std::string &text = like.headerTextAsStored();
+    put32(uint32_t(text.size()));
+    out.write(text.data(), text.size());
+    put32(uint32_t(like.targetNames().size()));
+    for (size_t i = 0; i < like.targetNames().size(); i++) {
+        const std::string &nm = like.targetNames()[i];
+        put32(uint32_t(nm.size() + 1));
+        out.write(nm.c_str(), nm.size() + 1);
+        put32(uint32_t(like.targetLengths()[i]));
+    }
+}
+
+void BamWriter::write(const std::vector<uint8_t> &record)
+{
+    const uint32_t v = uint32_t(record.size());
+    const uint8_t w[4] = {uint8_t(v), uint8_t(v >> 8), uint8_t(v >> 16), uint8_t(v >> 24)};
+    out.write(w, 4);
+    out.write(record.data(), record.size());
+}
+
 // ---------------- BAM record ----------------
 uint32_t BamRecord::calend() const
 {
@@ -168,6 +245,7 @@ BamFile::BamFile(const std::string &path) : fileName(path)
     const uint32_t l_text = le32(w);
     text.resize(l_text);
     if (l_text && !bgzf.read(&text[0], l_text)) throw std::string("truncated BAM header");
+    rawText = text;
     while (!text.empty() && text[text.size() - 1] == 0) text.erase(text.size() - 1);
     if (!bgzf.read(w, 4)) throw std::string("truncated BAM header");
     const uint32_t n_ref = le32(w);

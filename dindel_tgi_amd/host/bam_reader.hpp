@@ -58,11 +58,30 @@ private:
     BgzfReader(const BgzfReader &); BgzfReader &operator=(const BgzfReader &);
 };
 
+// BGZF output: blocks of at most 0xff00 input bytes, raw deflate, the "BC" extra field, CRC32 + ISIZE, and the empty block
+// that marks the end of the file (SAM/BAM specification §4.1) — what bam_open(fn, "wb") ... bam_close of libbam produces.
+class BgzfWriter {
+public:
+    BgzfWriter() : f(NULL) {}
+    ~BgzfWriter() { try { close(); } catch (...) {} }
+    void open(const std::string &path);                  // throws std::string("Cannot open bamfile PATH for writing!") like DInDel.cpp:678
+    void write(const void *src, size_t n);
+    void close();                                        // flushes, writes the end-of-file block
+private:
+    void flushBlock();
+    FILE *f;
+    std::vector<uint8_t> pending;
+    BgzfWriter(const BgzfWriter &); BgzfWriter &operator=(const BgzfWriter &);
+};
+
 class BamFile {
 public:
     explicit BamFile(const std::string &path);           // opens path and path + ".bai" (or path with .bam -> .bai); throws std::string("Cannot open BAM file.")
     int getTID(const std::string &name) const;           // throws std::string("Cannot find ID!") like MyBam::getTID
     const std::string &headerText() const { return text; }
+    const std::string &headerTextAsStored() const { return rawText; }     // the l_text bytes of the file, padding included (bam_header_write writes these)
+    // the undecoded record (without its 4-byte length) the traversal is looking at: valid inside a fetch callback / after next()
+    const std::vector<uint8_t> &rawRecord() const { return raw; }
     const std::vector<std::string> &targetNames() const { return names; }
     const std::vector<int32_t> &targetLengths() const { return lengths; }
     // bam_get_library: LB of the @RG line whose ID equals the record's RG tag; NULL if the tag or the library is missing
@@ -92,7 +111,7 @@ private:
     std::vector<Chunk> chunksFor(int tid, int beg, int end) const;
     void loadIndex(const std::string &path);
     BgzfReader bgzf;
-    std::string text;
+    std::string text, rawText;
     std::vector<std::string> names;
     std::vector<int32_t> lengths;
     std::map<std::string, int> strToTID;
@@ -125,6 +144,16 @@ template <class F> void BamFile::fetchImpl(int tid, int beg, int end, F callback
         }
     }
 }
+
+// bam_header_write + bam_write1: the header of `like` and then records given as their undecoded bytes
+class BamWriter {
+public:
+    BamWriter(const std::string &path, const BamFile &like);
+    void write(const std::vector<uint8_t> &record);      // block_size + the record
+    void close() { out.close(); }
+private:
+    BgzfWriter out;
+};
 
 } // namespace dindel
 #endif

@@ -3,7 +3,7 @@
 // Mirror of DetInDel::getCIGAR (reference DInDel.cpp:728-882): the read's hpos (position of every read base on the
 // haplotype, from the likelihood path) is composed with the haplotype's own alignment to the reference sequence
 // (Haplotype::ml.hpos, produced by the off-path alignHaplotypes step) and run-length encoded into BAM operations.
-// Writing the BAM record itself needs libbam and stays with the reference.
+// The BAM record is written by realigned_bam.cpp.
 #ifndef DINDEL_CIGAR_HPP
 #define DINDEL_CIGAR_HPP
 #include <utility>

@@ -22,6 +22,8 @@
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
 //   [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
 //   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D] [--quiet]
+//   [--outputRealignedBAM]   per window PREFIX.ra.INDEX_TID_LEFT_RIGHT.bam with the reads realigned through the most likely haplotype
+//                     pair (DInDel.cpp:589-620; main model only, like the reference; the haplotype file needs its A records)
 //   [--timing]        one "timing:" line on stdout with the busy time of each stage
 //   [--prepareOnly]   stop after the prepare stage (no likelihoods, no calls: profiling the read selection on a GPU-less host)
 #include <atomic>
@@ -41,6 +43,7 @@
 #include "diploid_glf.hpp"
 #include "get_reads.hpp"
 #include "glf_output.hpp"
+#include "realigned_bam.hpp"
 #include "window_io.hpp"
 
 using namespace dindel;
@@ -155,7 +158,7 @@ int main(int argc, char **argv)
         std::string a = argv[i];
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
         a = a.substr(2);
-        if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" ||
+        if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" || a == "outputRealignedBAM" ||
             a == "prepareOnly") opt[a] = "1";
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::cerr << "Option --" << a << " needs a value\n"; return 2; }
@@ -182,6 +185,8 @@ int main(int argc, char **argv)
         const double maxHapReadProd = num("maxHapReadProd", 10000000.0);
         const int batchWindows = std::max(1, int(num("batchWindows", 256)));
         const bool faster = has("faster"), oneBased = has("varFileIsOneBased"), prepareOnly = has("prepareOnly");
+        const bool realignedBAM = has("outputRealignedBAM") && !faster;                  // `params.outputRealignedBAM && params.slower`, :589
+        rsp.keepRecords = realignedBAM;
         unsigned hw = std::thread::hardware_concurrency();
         if (!hw) hw = 1;
         // defaults measured on a 16-CPU share of an MI355X host (profiles/r02/n2_pipeline.md): per window the read selection and
@@ -197,11 +202,12 @@ int main(int argc, char **argv)
             rsp.mapUnmappedReads = true;
             obs.mapUnmappedReads = true;
         }
-        { BamFile probe(opt["bamFile"]); }       // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens
+        const BamFile headerBam(opt["bamFile"]); // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
         HaplotypeFixture fixture(opt["hapFile"]);
         const int device = int(num("device", 0));
 
-        const std::string glfFile = opt["outputFile"] + ".glf.txt";
+        const std::string outputPrefix = opt["outputFile"];
+        const std::string glfFile = outputPrefix + ".glf.txt";
         std::ofstream glfOutput(glfFile.c_str());
         if (!glfOutput.is_open()) throw std::string("Cannot open file ").append(glfFile).append(" for writing.");
         OutputData glfData = makeGLFOutputData(glfOutput);
@@ -272,7 +278,7 @@ int main(int argc, char **argv)
                 LikelihoodEngine engine(obs, device);
                 engine.setThrowOnPositiveLikelihood(false);
                 // diploidGLF reads scalars and covered flags only; the --faster model's indel count (DInDel.cpp:3529) needs hpos
-                engine.setKeepAlignments(faster);
+                engine.setKeepAlignments(faster || realignedBAM);
                 if (packThreads > 0) engine.setHostThreads(packThreads);
                 while (toCompute.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -325,6 +331,15 @@ int main(int argc, char **argv)
                                     // like the reference, diploidGLF writes its lines as it goes: if it throws half-way ("genotyping
                                     // error"), the lines already written stay and the skipped-window line follows them
                                     diploidGLF(*T.haps, T.reads, J.result, T.pos, T.leftPos, T.rightPos, local, T.index, T.tid, T.candidates, dip, "dip");
+                                    if (realignedBAM) {                                      // DInDel.cpp:589-620
+                                        const std::pair<int, int> best = maxLikelihoodPair(*T.haps, T.reads, J.result, int(T.leftPos), T.candidates, dip);
+                                        std::vector<CIGAR> cigars;
+                                        realignedCigars(*T.haps, T.reads, J.result, best, int(T.leftPos), cigars);
+                                        std::vector<int> onHap(T.reads.size());
+                                        for (size_t r = 0; r < onHap.size(); r++) onHap[r] = J.result.onHap(r);
+                                        writeRealignedBAMFile(realignedBAMFileName(outputPrefix, T.index, T.tid, T.leftPos, T.rightPos, rsp.minReadOverlap),
+                                                              cigars, T.reads, onHap, headerBam);
+                                    }
                                 } catch (std::string &s) {
                                     T.message = skippedMessage(s);
                                     T.skipped = true;

@@ -12,6 +12,7 @@
 #define DINDEL_TYPES_HPP
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -126,6 +127,9 @@ public:
     explicit Haplotype(const std::string &s) : seq(s) {}
     std::string seq;
     std::map<int, AlignedVariant> indels, snps;   // variants of this haplotype w.r.t. the reference sequence
+    // hap.ml.hpos of the reference (Haplotype.hpp: `MLAlignment ml`, filled by alignHaplotypes): for every haplotype base its
+    // offset on the window's reference sequence, or a negative MLAlignment code.  Only getCIGAR reads it; empty = not aligned.
+    std::vector<int> refHpos;
     size_t size() const { return seq.size(); }
     const char &operator[](size_t i) const { return seq[i]; }
     // reference Haplotype.hpp:254-270
@@ -191,6 +195,8 @@ public:
     int32_t bamPos, bamMatePos;          // bam->core.pos, bam->core.mpos
     uint32_t endPos;                     // getEndPos(): bam_calend, or pos + 1 without a CIGAR (Read.hpp:185-188)
     int poolID;
+    // the BAM record behind the read (Read::bam), kept only when the realigned BAM is asked for (ReadSelectionParameters::keepRecords)
+    std::shared_ptr<const std::vector<uint8_t> > record;
     uint32_t getEndPos() const { return endPos; }
     int32_t getBAMMatePos() const { return bamMatePos; }
     // reverse() / complement() — Read.hpp:209-227 (getReads applies both to an unmapped read on its mate's strand)

@@ -193,14 +193,18 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                     const bool wanted = uint32_t(rec.pos) >= leftFetchReadPos;
                     if (wanted || (rec.flag & BAM_FPAIRED)) bam.complete(rec);      // name, bases, qualities; the RG tag of a paired read
                     try {
-                        if (wanted) readBuffer.push_back(makeRead(rec, bam, libraries, pool));
-                        else lookupLibrary(rec, bam, libraries, std::string());
+                        if (wanted) {
+                            readBuffer.push_back(makeRead(rec, bam, libraries, pool));
+                            if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
+                        } else lookupLibrary(rec, bam, libraries, std::string());
                         numReads++;
                     } catch (std::string &s) {
                         if (s.find("Cannot find library") == std::string::npos) throw;
                         numUnknownLib++;
-                        if (wanted) readBuffer.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
-                        else lookupLibrary(rec, bam, libraries, "single_end");
+                        if (wanted) {
+                            readBuffer.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
+                            if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
+                        } else lookupLibrary(rec, bam, libraries, "single_end");
                         numReads++;
                     }
                 }

@@ -15,8 +15,9 @@
 namespace dindel {
 
 struct ReadSelectionParameters {         // the DetInDel::Parameters fields getReads looks at (CLI defaults: DInDel.cpp:4122-4157)
-    ReadSelectionParameters() : maxReads(10000), maxReadLength(500), minReadOverlap(20), mapQualThreshold(0.99), mapUnmappedReads(false), quiet(true) {}
+    ReadSelectionParameters() : maxReads(10000), maxReadLength(500), minReadOverlap(20), mapQualThreshold(0.99), mapUnmappedReads(false), quiet(true), keepRecords(false) {}
     size_t maxReads; size_t maxReadLength; int minReadOverlap; double mapQualThreshold; bool mapUnmappedReads; bool quiet;
+    bool keepRecords;                    // Read::record = the read's BAM record (for --outputRealignedBAM)
 };
 
 // Read(const bam1_t *b, libraries, poolID, header, overrideLibName) — reference Read.hpp:120-183.  Throws std::string("Phred error.")

@@ -544,6 +544,7 @@ int ddh_glf_demo(const char *path, const char *thrown, const double *vals)
 // ---- N2: readers and the window's read selection ----
 #include "bam_reader.hpp"
 #include "get_reads.hpp"
+#include "realigned_bam.hpp"
 #include "window_io.hpp"
 
 extern "C" {
@@ -633,6 +634,35 @@ int ddh_fixture_json(const char *path, const int *indices, int n, char *out, int
         return emit(os.str(), out, cap);
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    }
+}
+
+// writeRealignedBAMFile on the records bam_fetch hands over for (tid, [beg, end)), in that order: read k gets the CIGAR
+// (op, len) pairs cig[cigOff[k] .. cigOff[k + 1]) with refPos[k] if onHap[k], else it is copied.  Returns the number of reads, or < 0.
+int ddh_write_realigned(const char *inBam, const char *tid, int beg, int end, const char *outBam, const int *onHap, const int *cig, const int *cigOff,
+                        const int *refPos, int n, char *err, int cap)
+{
+    try {
+        BamFile bam(inBam);
+        LibraryCollection libs;
+        std::vector<Read> reads;
+        bam.fetch(bam.getTID(tid), beg, end, [&](const BamRecord &b) -> bool {
+            reads.push_back(makeRead(b, bam, libs, 0, "single_end"));
+            reads.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
+            return true;
+        });
+        if (int(reads.size()) != n) { emit("read count differs", err, cap); return -int(reads.size()) - 1000; }
+        std::vector<CIGAR> cigars(reads.size());
+        std::vector<int> on(onHap, onHap + n);
+        for (int k = 0; k < n; k++) {
+            for (int i = cigOff[k]; i < cigOff[k + 1]; i++) cigars[size_t(k)].push_back(CIGAR::CIGOp(cig[2 * i], cig[2 * i + 1]));
+            cigars[size_t(k)].refPos = refPos[k];
+        }
+        writeRealignedBAMFile(outBam, cigars, reads, on, bam);
+        return n;
+    } catch (std::string &e) {
+        emit(e, err, cap);
+        return -1;
     }
 }
 

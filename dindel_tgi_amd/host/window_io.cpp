@@ -196,6 +196,11 @@ void parseFixtureStretch(const char *p, const char *end, int lineNo, const std::
         } else if (tag == "H") {
             if (!cur || tok.size() < 2) throw bad("Cannot read haplotype record");
             cur->haps.push_back(Haplotype(std::string(tok[1].first, tok[1].second)));
+        } else if (tag == "A") {                                       // the haplotype's own alignment to the reference: one number per base
+            if (!cur || cur->haps.empty()) throw bad("Cannot read haplotype alignment record");
+            std::vector<int> &v = cur->haps.back().refHpos;
+            v.clear();
+            for (size_t k = 1; k < tok.size(); k++) v.push_back(int(integer(k, "Cannot read haplotype alignment record")));
         } else if (tag == "V") {
             const char *what = "Cannot read variant record";
             if (!cur || cur->haps.empty() || tok.size() < 12) throw bad(what);

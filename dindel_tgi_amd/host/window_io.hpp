@@ -56,6 +56,8 @@ public:
 //   W <index> <leftPos> <rightPos>
 //   H <sequence>
 //   V I|S <key> <string> <startHap> <endHap> <startRead> <endRead> <leftFlankHap> <rightFlankHap> <leftFlankRead> <rightFlankRead>
+//   A <refpos of base 0> <refpos of base 1> ...      optional, after H: the haplotype's alignment to the window's reference
+//                                                    sequence (hap.ml.hpos; -1 = inserted base), needed by --outputRealignedBAM
 struct WindowHaplotypes {
     int index; uint32_t leftPos, rightPos;
     std::vector<Haplotype> haps;

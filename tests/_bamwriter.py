@@ -110,3 +110,41 @@ def write_bam(path, header_text, refs, records, block_bytes=3000):
             last = linear.get(w, last)            # empty windows repeat the previous offset, as samtools does
             bai += struct.pack("<Q", last)
     open(path + ".bai", "wb").write(bytes(bai))
+
+
+def read_bam(path):
+    """The whole file decoded: (header text as stored, [(name, length)], [record dict with tid / bin / raw fields as well]).  BGZF is a
+    series of gzip members, which the gzip module reads as one stream."""
+    import gzip
+    d = gzip.open(path, "rb").read()
+    assert d[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<I", d, 4)
+    text = d[8:8 + l_text].decode()
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<I", d, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<I", d, o)
+        name = d[o + 4:o + 4 + l_name - 1].decode()
+        ln, = struct.unpack_from("<I", d, o + 4 + l_name)
+        refs.append((name, ln))
+        o += 8 + l_name
+    recs = []
+    while o < len(d):
+        size, = struct.unpack_from("<I", d, o)
+        b = d[o + 4:o + 4 + size]
+        o += 4 + size
+        tid, pos, l_qname, mapq, bin_, n_cig, flag, l_seq, mtid, mpos, isize = struct.unpack_from("<iiBBHHHiiii", b, 0)
+        p = 32
+        qname = b[p:p + l_qname - 1].decode()
+        p += l_qname
+        cig = struct.unpack_from("<%dI" % n_cig, b, p)
+        p += 4 * n_cig
+        seq = "".join(NT16[(b[p + (i >> 1)] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
+        p += (l_seq + 1) // 2
+        qual = list(b[p:p + l_seq])
+        p += l_seq
+        recs.append(dict(tid=tid, pos=pos, qname=qname, mapq=mapq, bin=bin_, flag=flag, mtid=mtid, mpos=mpos, isize=isize, seq=seq, qual=qual,
+                         cigar="".join("%d%s" % (c >> 4, CIGAR_OPS[c & 15]) for c in cig), aux=bytes(b[p:]), raw=bytes(b)))
+    return text, refs, recs

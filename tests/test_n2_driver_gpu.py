@@ -59,11 +59,14 @@ def scene(tmp_path_factory):
             var = "-" + hap0[60:62]
             v1 = "V I 60 %s 60 61 59 60 60 61 59 60" % var            # deletion between haplotype bases 59 | 60
         windows.append("20 %d %d %d,%s" % (left, right, left + 60, var))
+        # A records: every haplotype base's offset on the window's reference sequence (hap.ml.hpos; -1 = inserted base)
+        a0 = "A " + " ".join(map(str, range(121)))
+        a1 = "A " + " ".join(map(str, list(range(60)) + ([-1, -1, -1] + list(range(60, 121)) if kind == "ins" else list(range(62, 121)))))
         if kind == "short":
             fixture += ["W %d %d %d" % (wi, left, right), "H ACG", "V I 60 *REF 60 60 60 60 60 60 60 60", "H " + hap1, v1]
         else:
-            fixture += ["W %d %d %d" % (wi, left, right), "H " + hap0, "V I 60 *REF 60 60 60 60 60 60 60 60", "V S 60 *REF 60 60 60 60 60 60 60 60",
-                        "H " + hap1, v1, "V S 60 *REF 60 60 60 60 60 60 60 60"]
+            fixture += ["W %d %d %d" % (wi, left, right), "H " + hap0, a0, "V I 60 *REF 60 60 60 60 60 60 60 60", "V S 60 *REF 60 60 60 60 60 60 60 60",
+                        "H " + hap1, v1, "V S 60 *REF 60 60 60 60 60 60 60 60"] + ([a1] if wi != 4 else [])     # window 4: the variant haplotype lacks its A record
         if kind == "empty":
             continue
         for _ in range(40):
@@ -97,7 +100,7 @@ def scene(tmp_path_factory):
     open(vf, "w").write("\n".join(windows) + "\n")
     open(hf, "w").write("\n".join(fixture) + "\n")
     subprocess.check_call(["make", "-s", "-C", HOST])
-    return dict(tmp=tmp, ref=ref, fasta=fasta, bam=bam, vf=vf, hf=hf, spec=spec)
+    return dict(tmp=tmp, ref=ref, fasta=fasta, bam=bam, vf=vf, hf=hf, spec=spec, recs=recs)
 
 
 def run_driver(scene, prefix, *extra):
@@ -184,3 +187,71 @@ def test_driver_faster_model_runs_the_same_loop(scene):
     dm = [r for r in rows if r["analysis_type"] == "dip.map"]
     assert [int(r["index"]) for r in dm] == [1, 2, 3, 4] and all(float(r["qual"]) > 20 for r in dm)
     assert [r["msg"] for r in rows if r["index"] == "5"] == ["error_hapSize_error."]
+
+
+def clip_to_window(pos, cigar, left, right):
+    """The truth alignment as a realignment inside [left, right] can state it: read bases on reference positions outside the window's
+    haplotypes hang off them (LO / RO) and come out soft-clipped; the position is that of the first base kept."""
+    ops, ref, out, new_pos = bw.parse_cigar(cigar), pos, [], None
+    for l, op in ops:
+        if op == 0:                                           # M: split into clipped | kept | clipped
+            lo = max(0, min(l, left - ref)); hi = max(0, min(l, ref + l - (right + 1)))
+            for n, o in ((lo, 4), (l - lo - hi, 0), (hi, 4)):
+                if n:
+                    if o == 0 and new_pos is None:
+                        new_pos = ref + lo
+                    out.append([n, o])
+            ref += l
+        else:
+            out.append([l, op])
+            if op == 2:
+                ref += l
+    merged = []
+    for n, o in out:
+        if merged and merged[-1][1] == o:
+            merged[-1][0] += n
+        else:
+            merged.append([n, o])
+    return new_pos, "".join("%d%s" % (n, bw.CIGAR_OPS[o]) for n, o in merged)
+
+
+def test_driver_writes_realigned_bam(scene):
+    """--outputRealignedBAM (DInDel.cpp:589-620, :670-725): one BAM per window with every read of the window, realigned through the
+    better haplotype of the most likely pair.  The sample's reads were cut from the two haplotypes, so for a read with enough sequence
+    on both sides of the event the new record must say where it came from: position and CIGAR of the truth."""
+    path, rows = run_driver(scene, "ra", "--outputRealignedBAM")
+    assert [r["msg"] for r in rows if r["index"] == "4"][-1] == "error_Haplotype_has_not_been_aligned!"
+    plain = open(run_driver(scene, "ra0")[0]).read().split("\n")
+    with_bam = open(path).read().split("\n")
+    # window 4 wrote its calls and then failed in getCIGAR: the skipped line follows them, as in the reference's catch
+    assert [l for l in with_bam if not l.startswith("error_Haplotype")] == plain
+    truth = {r["qname"]: r for r in scene["recs"]}
+    header0, refs0, _ = bw.read_bam(scene["bam"])
+    seen = 0
+    for wi, (left, kind, _frac) in enumerate(scene["spec"], start=1):
+        name = "%s.ra.%d_20_%d_%d.bam" % (str(scene["tmp"] / "ra"), wi, left + 20, left + 120 - 20)
+        if wi >= 4:
+            assert not os.path.exists(name)                  # getCIGAR threw / the window was skipped before
+            continue
+        header, refs, recs = bw.read_bam(name)
+        assert (header, refs) == (header0, refs0)
+        kept = [dict(zip(GLF_COLUMNS, l.split(" "))) for l in with_bam if l.split(" ")[1:2] == [str(wi)] and " dip.map " in l]
+        assert len(recs) == int(kept[0]["num_reads"])
+        n_event = 0
+        for r in recs:
+            t = truth[r["qname"]]
+            assert (r["seq"], r["qual"], r["flag"], r["mapq"], r["mpos"]) == (t["seq"], t["qual"], t["flag"], t["mapq"], t["mpos"])
+            assert sum(l for l, op in bw.parse_cigar(r["cigar"]) if op in (0, 1, 4)) == 100
+            assert r["isize"] == r["pos"] - r["mpos"]
+            cig = bw.parse_cigar(t["cigar"])
+            if len(cig) == 3 and min(cig[0][0], cig[2][0]) >= 12:          # the event with 12 bases either side
+                assert (r["pos"], r["cigar"]) == clip_to_window(t["pos"], t["cigar"], left, left + 120), (wi, r["qname"])
+                n_event += 1
+            elif len(cig) == 1 and t["pos"] + 100 <= left + 60 - 5:        # ends left of the event
+                assert (r["pos"], r["cigar"]) == clip_to_window(t["pos"], "100M", left, left + 120), (wi, r["qname"])
+        assert n_event >= 5
+        seen += 1
+    assert seen == 3
+    # --faster has no realigned output, like the reference (`params.outputRealignedBAM && params.slower`)
+    run_driver(scene, "raf", "--outputRealignedBAM", "--faster")
+    assert not [f for f in os.listdir(str(scene["tmp"])) if f.startswith("raf.ra.")]

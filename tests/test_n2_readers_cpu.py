@@ -310,3 +310,55 @@ def test_haplotype_fixture_file_large_and_broken(lib, tmp_path):
     open(path, "w").write("H ACGT\n")
     assert call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot read haplotype record in line 1 of %s" % path}
     assert call_json(lib.ddh_fixture_json, str(tmp_path / "nope").encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot open haplotype file %s" % (tmp_path / "nope")}
+
+
+def test_realigned_bam_writer_round_trip(lib, tmp_path):
+    """writeRealignedBAMFile (DInDel.cpp:670-725) on the own BGZF writer: the header is the input's; a read placed on a haplotype gets
+    the new CIGAR, pos = refPos and isize = refPos - mpos with its bin, name, bases, qualities and tags untouched; the others are copied
+    byte for byte.  The output is read back with Python's gzip (BGZF = a series of gzip members ending in the empty block)."""
+    rng = np.random.default_rng(31)
+    header = "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:250000\n@RG\tID:g1\tSM:s\tLB:libA\n"
+    recs = [r for r in random_records(rng, 900, 250000, ["g1"]) if not (r["flag"] & 4)]
+    path, out = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bw.write_bam(path, header, [("20", 250000)], [(0, r) for r in recs], block_bytes=3000)
+    beg, end = 20000, 200000
+    inside = [r for r in recs if r["pos"] + bw.ref_len(bw.parse_cigar(r["cigar"])) > beg and r["pos"] < end]
+    assert len(inside) > 400                                  # > 64 KB of records: several BGZF blocks
+    on = [int(rng.random() < 0.7) for _ in inside]
+    new_cigs, ref_pos = [], []
+    for r in inside:
+        L = len(r["seq"])
+        a = int(rng.integers(1, L - 1))
+        pick = int(rng.integers(0, 4))
+        new_cigs.append([[(0, L)], [(4, a), (0, L - a)], [(0, a), (2, int(rng.integers(1, 40))), (0, L - a)], [(0, a), (1, 1), (0, L - a - 1)]][pick])
+        ref_pos.append(int(rng.integers(-1, 240000)))
+    off = np.cumsum([0] + [len(c) for c in new_cigs]).astype(np.int32)
+    flat = np.array([v for c in new_cigs for op in c for v in op], dtype=np.int32)
+    lib.ddh_write_realigned.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(256)
+    as_p = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    n = lib.ddh_write_realigned(path.encode(), b"20", beg, end, out.encode(), as_p(on), as_p(flat), as_p(off), as_p(ref_pos), len(inside), err, 256)
+    assert n == len(inside), err.value
+    text0, refs0, recs0 = bw.read_bam(path)
+    text1, refs1, recs1 = bw.read_bam(out)
+    assert (text1, refs1) == (text0, refs0) == (header, [("20", 250000)])
+    assert open(out, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # the end-of-file block
+    orig = {r["qname"]: r for r in recs0}
+    assert [r["qname"] for r in recs1] == [r["qname"] for r in inside]
+    for r1, flag, cig, rp in zip(recs1, on, new_cigs, ref_pos):
+        r0 = orig[r1["qname"]]
+        if not flag:
+            assert r1["raw"] == r0["raw"]
+            continue
+        assert r1["cigar"] == "".join("%d%s" % (l, bw.CIGAR_OPS[op]) for op, l in cig)
+        assert (r1["pos"], r1["isize"]) == (rp, rp - r0["mpos"])
+        for k in ("tid", "qname", "mapq", "bin", "flag", "mtid", "mpos", "seq", "qual", "aux"):
+            assert r1[k] == r0[k], k
+    # what the reference checks before writing
+    n = lib.ddh_write_realigned(path.encode(), b"20", beg, end, str(tmp_path / "no_such_dir" / "x.bam").encode(), as_p(on), as_p(flat), as_p(off), as_p(ref_pos),
+                                len(inside), err, 256)
+    assert n == -1 and err.value.decode() == "Cannot open bamfile %s for writing!" % (tmp_path / "no_such_dir" / "x.bam")
+    # the reader reads what the writer wrote, index-free
+    got = call_json(lib.ddh_bam_fetch_json, path.encode(), b"20", -1, 0)
+    assert len(got["records"]) == len(recs0)
