@@ -15,7 +15,9 @@ FILES = ["include/dindel_hmm.h", "oracle/dd_oracle.c", "oracle/dd_oracle.h", "or
          "dindel_tgi_amd/host/glf_to_vcf.hpp", "dindel_tgi_amd/host/glf_to_vcf.cpp", "dindel_tgi_amd/host/bam_reader.hpp",
          "dindel_tgi_amd/host/window_io.hpp", "dindel_tgi_amd/host/window_io.cpp", "dindel_tgi_amd/host/get_reads.hpp",
          "dindel_tgi_amd/host/get_reads.cpp", "dindel_tgi_amd/host/diploid_glf.hpp", "dindel_tgi_amd/host/diploid_glf.cpp",
-         "dindel_tgi_amd/host/dindel_gpu.cpp", "dindel_tgi_amd/host/dindel_glf2vcf.cpp", "tests/_vcf_oracle.py", "profiles/r02/instruction_mix.md"]
+         "dindel_tgi_amd/host/dindel_gpu.cpp", "dindel_tgi_amd/host/dindel_glf2vcf.cpp", "tests/_vcf_oracle.py", "profiles/r02/instruction_mix.md",
+         "dindel_tgi_amd/host/realigned_bam.hpp", "dindel_tgi_amd/host/realigned_bam.cpp", "dindel_tgi_amd/host/bam_reader.cpp",
+         "tests/_getreads_oracle.py", "profiles/r02/n2_pipeline.md"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
