@@ -21,7 +21,7 @@
 //   --bamFile F --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
 //   [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
-//   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D] [--quiet]
+//   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D | --devices D0,D1,...] [--quiet]
 //   [--outputRealignedBAM]   per window PREFIX.ra.INDEX_TID_LEFT_RIGHT.bam with the reads realigned through the most likely haplotype
 //                     pair (DInDel.cpp:589-620; main model only, like the reference; the haplotype file needs its A records)
 //   [--timing]        one "timing:" line on stdout with the busy time of each stage
@@ -193,7 +193,19 @@ int main(int argc, char **argv)
         // diploidGLF cost about the same CPU time, two engines keep the GPU busy while one of them packs
         const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
         const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
-        const int computeThreads = std::max(1, int(num("computeThreads", hw >= 8 ? 2.0 : 1.0)));
+        // --devices 0,1,...: the engines are dealt out over these GPUs (batches are independent: no exchange between devices)
+        std::vector<int> devices;
+        {
+            std::string list = has("devices") ? opt["devices"] : (has("device") ? opt["device"] : std::string("0"));
+            for (size_t i = 0; i <= list.size();) {
+                size_t e = list.find(',', i);
+                if (e == std::string::npos) e = list.size();
+                if (e > i) devices.push_back(atoi(list.substr(i, e - i).c_str()));
+                i = e + 1;
+            }
+            if (devices.empty()) devices.push_back(0);
+        }
+        const int computeThreads = std::max(1, int(num("computeThreads", (hw >= 8 ? 2.0 : 1.0) * double(devices.size()))));
         const int packThreads = int(num("packThreads", double(std::min(4u, std::max(1u, hw / 4)))));   // host threads of each engine's packing (0: the engine's default)
 
         LibraryCollection libraries;
@@ -204,7 +216,6 @@ int main(int argc, char **argv)
         }
         const BamFile headerBam(opt["bamFile"]); // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
         HaplotypeFixture fixture(opt["hapFile"]);
-        const int device = int(num("device", 0));
 
         const std::string outputPrefix = opt["outputFile"];
         const std::string glfFile = outputPrefix + ".glf.txt";
@@ -275,7 +286,7 @@ int main(int argc, char **argv)
         for (int ct = 0; ct < computeThreads; ct++) computeWorkers.push_back(std::thread([&, ct]() {
             BatchPtr b;
             try {
-                LikelihoodEngine engine(obs, device);
+                LikelihoodEngine engine(obs, devices[size_t(ct) % devices.size()]);
                 engine.setThrowOnPositiveLikelihood(false);
                 // diploidGLF reads scalars and covered flags only; the --faster model's indel count (DInDel.cpp:3529) needs hpos
                 engine.setKeepAlignments(faster || realignedBAM);

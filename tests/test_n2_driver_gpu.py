@@ -170,6 +170,9 @@ def test_driver_batching_is_exact_and_vcf_follows(scene):
     d = open(run_driver(scene, "b2p", "--batchWindows", "2", "--prepareThreads", "4", "--reduceThreads", "3")[0]).read()
     e = open(run_driver(scene, "b1p", "--batchWindows", "1", "--prepareThreads", "1", "--reduceThreads", "1")[0]).read()
     assert a == d == e
+    # the engines dealt out over a device list (here the same GPU twice: one box, one card)
+    f = open(run_driver(scene, "b2d", "--batchWindows", "2", "--devices", "0,0", "--computeThreads", "3")[0]).read()
+    assert a == f
     lst = str(scene["tmp"] / "glfs.txt")
     open(lst, "w").write(str(scene["tmp"] / "b64.glf.txt") + "\n")
     vcf = str(scene["tmp"] / "calls.vcf")
