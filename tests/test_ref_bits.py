@@ -49,11 +49,21 @@ def test_add_logs(ref):
     h = _host.load(); h.ddh_add_logs.restype = C.c_double; h.ddh_add_logs.argtypes = [C.c_double, C.c_double]
     rng = np.random.default_rng(2)
     vals = np.concatenate([-rng.random(300) * 800, [-0.0, 0.0, -1e-300, -745.2, -1e4, -np.inf]])
-    for a in vals[:60]:
-        for b in vals:
-            want = ref.ref_add_logs(a, b)
-            for got in (o.ddo_add_logs(a, b), h.ddh_add_logs(a, b)):
-                assert got == want or (math.isnan(got) and math.isnan(want)), (a, b)
+    pairs = [(a, b) for a in vals[:60] for b in vals]
+    # the host mirror answers equal arguments and arguments more than 36.75 apart without exp / log: the neighbourhood of both
+    # shortcuts, signed zeros, infinities and NaN
+    base = [-1e-9, -3.5, -123.456, -700.0, 0.0, -0.0, 5.0]
+    for a in base:
+        pairs += [(a, a), (a, np.nextafter(a, -np.inf)), (np.nextafter(a, -np.inf), a)]
+        for d in (36.0, 36.7, 36.73, 36.7368, 36.74, 36.7499999, 36.75, np.nextafter(36.75, 40.0), 36.76, 37.0, 40.0, 745.0, 1e6):
+            pairs += [(a, a - d), (a - d, a)]
+    special = [np.inf, -np.inf, np.nan, 0.0, -0.0, -1.0]
+    pairs += [(a, b) for a in special for b in special]
+    same = lambda x, y: (x == y and math.copysign(1.0, x) == math.copysign(1.0, y)) or (math.isnan(x) and math.isnan(y))
+    for a, b in pairs:
+        want = ref.ref_add_logs(a, b)
+        for got in (o.ddo_add_logs(a, b), h.ddh_add_logs(a, b)):
+            assert same(got, want), (a, b, got, want)
 
 
 def test_aligned_variant_mirror(ref):
