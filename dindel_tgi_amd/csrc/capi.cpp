@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -279,6 +280,7 @@ struct DevBuf {
 
 static thread_local int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per host thread, like the cache and the error string
 static thread_local char g_kernel_name[64] = "dd_hmm_kernel";
+static thread_local int g_last_direct = 0;     // output arrays the last host-pointer call on this thread let the kernels write in place
 
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
@@ -296,6 +298,8 @@ const char *dd_kernel_name(void)
     else if (K > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_faster_kernel");
     return g_kernel_name;
 }
+
+int dd_last_direct_outputs(void) { return g_last_direct; }
 
 void dd_last_launch(int32_t out[8])
 {   // K, D build, waves per workgroup, LDS bytes per workgroup, grid, read split, LDS per wave, shared LDS
@@ -1047,8 +1051,50 @@ int dd_compute_likelihoods_faster(const dd_params *p, const dd_batch *b, dd_resu
     return compute_likelihoods_impl(MODEL_S, p, b, r, device);
 }
 
+namespace {
+// true iff some p[i] >= limit.  The arrays checked this way hold one byte per read base (2e8 for configs[1]): a branch-free
+// pass the compiler vectorises, cut into pieces for a few threads when it is long.
+bool any_at_or_above(const uint8_t *p, size_t n, unsigned limit)
+{
+    if (limit > 255 || n == 0) return false;
+    auto scan = [p, limit](size_t lo, size_t hi) -> unsigned {
+        unsigned bad = 0;
+        for (size_t i = lo; i < hi; i++) bad |= (unsigned)(p[i] >= limit);
+        return bad;
+    };
+    const size_t piece = (size_t)8 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), (n + piece - 1) / piece);
+    if (nt <= 1) return scan(0, n) != 0;
+    std::vector<unsigned> bad(nt, 0);
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) th.emplace_back([&, t]() { bad[t] = scan(n * t / nt, n * (t + 1) / nt); });
+    bad[0] = scan(0, n / nt);
+    for (auto &x : th) x.join();
+    for (size_t t = 0; t < nt; t++) if (bad[t]) return true;
+    return false;
+}
+
+// DD_TIMING=1: where a host-pointer call spends its time outside the kernels (stderr, one line per call)
+struct StageClock {
+    bool on; std::chrono::steady_clock::time_point t; std::string line;
+    StageClock() : on(getenv("DD_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const std::chrono::steady_clock::time_point n = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof(buf), " %s=%.2fms", what, std::chrono::duration<double, std::milli>(n - t).count());
+        line += buf;
+        t = n;
+    }
+    ~StageClock() { if (on) fprintf(stderr, "dd_timing:%s\n", line.c_str()); }
+};
+}
+
 static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
+    StageClock clk;
     int rc = check_params(p);
     if (rc) return rc;
     if (!r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
@@ -1069,8 +1115,10 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     if (n_skip < 0) return n_skip;
     sz.max_hap_len = ok_max[0] > 0 ? ok_max[0] : 1;      // planning maxima: the windows that are computed
     sz.max_read_len = ok_max[1] > 0 ? ok_max[1] : 1;
+    clk.mark("screen");
     uint8_t sym_lut[256];
     if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
+    clk.mark("symbols");
     std::vector<double> lib_logprob, lib_log95;
     if (p->mapUnmappedReads && model == MODEL_FBMAXERR) {
         if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib)
@@ -1082,15 +1130,14 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         for (int64_t q = 0; q < sz.n_reads; q++)
             if (b->read_lib[q] >= b->n_libs) return fail(DD_ERR_INVALID, "read_lib out of range");
     }
-    for (int64_t q = 0; q < sz.n_reads; q++)
-        if (b->read_mqidx[q] >= b->n_mapq) return fail(DD_ERR_INVALID, "read_mqidx out of range");
-    for (int64_t i = 0; i < sz.read_bases; i++)
-        if (b->read_qidx[i] >= b->n_qual) return fail(DD_ERR_INVALID, "read_qidx out of range");
+    if (any_at_or_above(b->read_mqidx, (size_t)sz.n_reads, (unsigned)b->n_mapq)) return fail(DD_ERR_INVALID, "read_mqidx out of range");
+    if (any_at_or_above(b->read_qidx, (size_t)sz.read_bases, (unsigned)b->n_qual)) return fail(DD_ERR_INVALID, "read_qidx out of range");
     for (int i = 0; i < b->n_qual; i++)
         if (!(b->qual_table[i] >= 0.0 && b->qual_table[i] <= 1.0)) return fail(DD_ERR_INVALID, "base quality outside [0,1]");
     for (int i = 0; i < b->n_mapq; i++)
         if (!(b->mapq_table[i] >= 0.0 && b->mapq_table[i] < 1.0)) return fail(DD_ERR_INVALID, "mapping quality outside [0,1)");
 
+    clk.mark("validate");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(DD_ERR_NO_DEVICE, "no HIP device: the likelihood path has no CPU fallback");
@@ -1171,6 +1218,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     }
     const bool single_class = model == MODEL_S || (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
 
+    clk.mark("plan");
     // ---- device arena (cached per host thread) ----
     const size_t np = (size_t)sz.n_pairs;
     const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
@@ -1182,6 +1230,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
     DeviceCtx &ctx = g_ctx.c;
     if ((rc = ctx.reserve(device, in_bytes + out_bytes + 2 * (ws_bytes + 256), staged ? in_bytes + out_bytes : 0))) return rc;
+    clk.mark("reserve");
     DevBuf dev(ctx);
     dev.staged = staged;
 #define UP(field, n) if ((rc = dev.upload(&db.field, b->field, (size_t)(n)))) return rc
@@ -1215,16 +1264,44 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
             if (!hc.haps.empty() && (rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;
     if ((rc = dev.flush_uploads(ctx.s[0]))) return rc;       // staged mode: the one H2D copy
     if (!staged) HIP_TRY(hipStreamSynchronize(nullptr));     // pageable uploads went through the null stream's DMA
+    clk.mark("upload");
 
     dd_result dr;
     memset(&dr, 0, sizeof(dr));
     const size_t out_begin = DevBuf::align(dev.used);
-#define OUT(field, n) if (r->field && (rc = dev.alloc(&dr.field, (size_t)(n)))) return rc
+    // Output arrays the caller keeps in page-locked host memory that this device can address (dd_host_alloc, hipHostMalloc) are
+    // written by the kernels themselves, over the link, as the pairs finish: no staging copy in HBM and no copy afterwards.
+    // (The runtime carries device -> host copies of this size out with a copy KERNEL: profiles/r02/hostapi_timeline.txt shows
+    // 300 ms of such kernels on the CUs beside 410 ms of HMM kernels for configs[1].)  status and offHapHMQ stay in HBM: the
+    // onHap kernel reads them back.  DD_ZERO_COPY=0 switches this off (A/B).
+    static const bool zero_copy_on = !(getenv("DD_ZERO_COPY") && !strcmp(getenv("DD_ZERO_COPY"), "0"));
+    auto mapped = [&](void *host, size_t bytes) -> void * {
+        if (!zero_copy_on || !host || !bytes) return nullptr;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+        hipPointerAttribute_t e;                                   // the last byte belongs to the same registered range
+        if (hipPointerGetAttributes(&e, static_cast<unsigned char *>(host) + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (e.type != hipMemoryTypeHost || !e.devicePointer ||
+            static_cast<unsigned char *>(e.devicePointer) - static_cast<unsigned char *>(a.devicePointer) != (ptrdiff_t)(bytes - 1)) return nullptr;
+        return a.devicePointer;
+    };
+    struct { bool ll, llOn, llOff, mLogBQ, offHap, numIndels, numMismatch, nBQT, nmmBQT, nMMLeft, nMMRight, firstBase, lastBase, hpos, var_covered,
+             status, onHap, var_fcov, offHapHMQ; } direct;
+    memset(&direct, 0, sizeof(direct));
+    int n_direct = 0;
+#define OUT(field, n) if (r->field) { \
+        void *m = mapped(r->field, (size_t)(n) * sizeof(*r->field)); \
+        if (m) { dr.field = static_cast<decltype(dr.field)>(m); direct.field = true; n_direct++; } \
+        else if ((rc = dev.alloc(&dr.field, (size_t)(n)))) return rc; }
+#define OUT_DEVICE(field, n) if (r->field && (rc = dev.alloc(&dr.field, (size_t)(n)))) return rc
     OUT(ll, np); OUT(llOn, np); OUT(llOff, np); OUT(mLogBQ, np); OUT(offHap, np); OUT(numIndels, np);
     OUT(numMismatch, np); OUT(nBQT, np); OUT(nmmBQT, np); OUT(nMMLeft, np); OUT(nMMRight, np); OUT(firstBase, np);
-    OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT(status, np); OUT(onHap, sz.n_reads);
+    OUT(lastBase, np); OUT(hpos, sz.hpos_len); OUT(var_covered, sz.var_cov_len); OUT_DEVICE(status, np); OUT(onHap, sz.n_reads);
     OUT(var_fcov, sz.var_cov_len);
 #undef OUT
+#undef OUT_DEVICE
+    g_last_direct = n_direct;
     if ((r->offHapHMQ || r->onHap) && (rc = dev.alloc(&dr.offHapHMQ, np))) return rc;   // onHap is derived from it
     const size_t out_end = dev.used;
     unsigned char *ws[2] = {nullptr, nullptr};
@@ -1249,7 +1326,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         cw[c] = w;
     }
     cw[n_chunks] = W;
-#define DOWN(field, off, n) if (r->field && (n)) HIP_TRY(hipMemcpyAsync(r->field + (off), dr.field + (off), (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost, st))
+#define DOWN(field, off, n) if (r->field && (n) && !direct.field) HIP_TRY(hipMemcpyAsync(r->field + (off), dr.field + (off), (size_t)(n) * sizeof(*r->field), hipMemcpyDeviceToHost, st))
     auto download = [&](int c) -> int {
         hipStream_t st = streams.s[c & 1];
         const int w0 = cw[c], w1 = cw[c + 1];
@@ -1294,7 +1371,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     if (staged) {
         HIP_TRY(hipMemcpyAsync(ctx.pinned + out_begin, ctx.arena + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, streams.s[0]));
         HIP_TRY(hipStreamSynchronize(streams.s[0]));
-#define BACK(field, n) if (r->field && (n)) memcpy(r->field, ctx.pinned + (reinterpret_cast<unsigned char *>(dr.field) - ctx.arena), (size_t)(n) * sizeof(*r->field))
+#define BACK(field, n) if (r->field && (n) && !direct.field) memcpy(r->field, ctx.pinned + (reinterpret_cast<unsigned char *>(dr.field) - ctx.arena), (size_t)(n) * sizeof(*r->field))
         BACK(ll, np); BACK(llOn, np); BACK(llOff, np); BACK(mLogBQ, np); BACK(offHap, np); BACK(offHapHMQ, np);
         BACK(numIndels, np); BACK(numMismatch, np); BACK(nBQT, np); BACK(nmmBQT, np); BACK(nMMLeft, np); BACK(nMMRight, np);
         BACK(firstBase, np); BACK(lastBase, np); BACK(status, np); BACK(hpos, sz.hpos_len); BACK(var_covered, sz.var_cov_len);
@@ -1308,7 +1385,9 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     return DD_SUCCESS;
     };
 #undef DOWN
+    clk.mark("outputs");
     rc = enqueue_and_collect();
+    clk.mark("run");
     if (rc != DD_SUCCESS) {
         // kernels / copies already enqueued keep writing into the caller's buffers and this thread's arena: drain both
         // streams before the error is reported, so that neither is reused while still in flight

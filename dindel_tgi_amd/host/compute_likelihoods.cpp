@@ -229,8 +229,10 @@ struct BatchBlock {
 struct PackScratch {
     std::vector<int32_t> hap_seq_off, hap_var, hap_var_flank;
     std::vector<uint32_t> win_hap_start, read_start;
-    std::vector<char> hap_seq, read_seq;
-    std::vector<uint8_t> read_qidx, read_mqidx, read_flags, read_lib;
+    std::vector<char> hap_seq;
+    RawBuf<char> read_seq;               // the two big inputs (one byte per read base each) sit in page-locked memory: their
+    RawBuf<uint8_t> read_qidx;           // H2D copy then runs at link speed instead of through the driver's staging buffers
+    std::vector<uint8_t> read_mqidx, read_flags, read_lib;
     std::vector<int32_t> read_mate_pos, read_mate_len;
 };
 
@@ -563,8 +565,8 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
             throw std::string("batch too large: more than 2^31 haplotype or read bases (split the windows over several calls)");
     }
     const size_t n_haps = size_t(B.win_hap_off[W]), n_reads = size_t(B.win_read_off[W]), n_var = size_t(B.hap_var_off[n_haps]);
-    S.win_hap_start.resize(size_t(W)); S.hap_seq.resize(size_t(n_hap_bases) + 1); S.read_seq.resize(size_t(n_read_bases) + 1);
-    S.read_qidx.resize(size_t(n_read_bases) + 1); S.read_mqidx.resize(n_reads + 1); S.read_start.resize(n_reads + 1);
+    S.win_hap_start.resize(size_t(W)); S.hap_seq.resize(size_t(n_hap_bases) + 1); S.read_seq.reserve(size_t(n_read_bases) + 1);
+    S.read_qidx.reserve(size_t(n_read_bases) + 1); S.read_mqidx.resize(n_reads + 1); S.read_start.resize(n_reads + 1);
     S.read_flags.resize(n_reads + 1); S.hap_var.resize(2 * n_var + 1); S.hap_var_flank.resize(3 * n_var + 1);
     if (with_mates) { S.read_mate_pos.resize(n_reads + 1); S.read_mate_len.resize(n_reads + 1); }
 
@@ -596,8 +598,8 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
                 const Read &R = (*J.reads)[r];
                 const size_t q = size_t(B.win_read_off[w]) + r;
                 const size_t so = size_t(B.read_seq_off[q]);
-                memcpy(S.read_seq.data() + so, R.seq.seq.data(), R.size());
-                uint8_t *qi = S.read_qidx.data() + so;
+                memcpy(S.read_seq.p + so, R.seq.seq.data(), R.size());
+                uint8_t *qi = S.read_qidx.p + so;
                 double lastq = -1.0;
                 int lastidx = 0;
                 for (size_t b = 0; b < R.qual.size(); b++) {
@@ -645,7 +647,7 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     Bt.hap_seq_off = S.hap_seq_off.data(); Bt.hap_seq = S.hap_seq.data(); Bt.hap_var_off = B.hap_var_off.data();
     Bt.hap_var = n_var ? S.hap_var.data() : NULL;
     Bt.hap_var_flank = n_var ? S.hap_var_flank.data() : NULL;
-    Bt.read_seq_off = B.read_seq_off.data(); Bt.read_seq = S.read_seq.data(); Bt.read_qidx = S.read_qidx.data();
+    Bt.read_seq_off = B.read_seq_off.data(); Bt.read_seq = S.read_seq.p; Bt.read_qidx = S.read_qidx.p;
     Bt.read_mqidx = S.read_mqidx.data(); Bt.read_start = S.read_start.data(); Bt.read_flags = S.read_flags.data();
     double one_q = 0.5;
     Bt.n_qual = int(qtab.tab.size()); Bt.qual_table = qtab.tab.empty() ? &one_q : qtab.tab.data();

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 9
+#define DD_ABI_VERSION 10
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -342,6 +342,10 @@ const char *dd_kernel_name(void);
 /* geometry of the last dd_launch_device on this host thread's library instance:
  * {K positions/lane, D build, waves/workgroup, LDS bytes/workgroup, grid, read split, LDS bytes/wave, shared LDS bytes} */
 void dd_last_launch(int32_t out[8]);
+/* How many output arrays of the last dd_compute_likelihoods / _faster call on this host thread were written by the kernels directly
+ * into the caller's memory: arrays that lie in page-locked, device-addressable host memory (dd_host_alloc, hipHostMalloc) are
+ * not staged in HBM and not copied afterwards (status and offHapHMQ excepted).  0 for pageable memory. */
+int dd_last_direct_outputs(void);
 const char *dd_last_error(void);
 int dd_abi_version(void);
 int dd_device_count(void);

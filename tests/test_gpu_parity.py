@@ -122,3 +122,42 @@ def test_device_pointer_path_matches_host_path(lib):
         dev.launch()
     s.synchronize()
     assert_same(dev.results(), run_host_api(lib, p, pb), pb)
+
+
+@pytest.mark.parametrize("n_windows, faster", [(6, False), (400, False), (6, True), (400, True)])
+def test_pinned_outputs_are_written_in_place(lib, n_windows, faster):
+    """Output arrays in page-locked host memory (dd_host_alloc) are stored by the kernels directly — no copy in HBM, no copy back;
+    pageable arrays go through HBM and a device -> host copy.  Both ways give the same bytes, for a small batch (one staged
+    transfer) and for one above the 64 MB staging limit (chunked, double-buffered), for both models."""
+    from dindel_tgi_amd.batch import result_lengths, RESULT_DTYPES
+    pb = synth.generate(n_windows, H=8, R=150, L=100, hap_len=120, seed=21, mixed_quals=True)
+    p = capi.params_cli_defaults()
+    call = lib.dd_compute_likelihoods_faster if faster else lib.dd_compute_likelihoods
+    arrs, res = alloc_result(pb, fill=None)
+    b = pb.ctypes_batch()
+    assert call(C.byref(p), C.byref(b), C.byref(res), 0) == 0, capi.last_error()
+    assert lib.dd_last_direct_outputs() == 0
+    lib.dd_host_alloc.restype = C.c_void_p
+    lib.dd_host_alloc.argtypes = [C.c_size_t]
+    lib.dd_host_free.argtypes = [C.c_void_p]
+    n = result_lengths(pb)
+    pinned, res2, ptrs = {}, capi.dd_result(), []
+    for k, typ in capi.RESULT_FIELDS:
+        dt = np.dtype(RESULT_DTYPES[k])
+        cnt = max(n[k], 1)
+        ptr = lib.dd_host_alloc(cnt * dt.itemsize)
+        assert ptr
+        ptrs.append(ptr)
+        pinned[k] = np.frombuffer((C.c_char * (cnt * dt.itemsize)).from_address(ptr), dtype=dt)
+        pinned[k][...] = 0x55 if dt.kind != "f" else -1.25
+        setattr(res2, k, C.cast(C.c_void_p(ptr), typ))
+    try:
+        assert call(C.byref(p), C.byref(b), C.byref(res2), 0) == 0, capi.last_error()
+        assert lib.dd_last_direct_outputs() >= 10
+        for k, _typ in capi.RESULT_FIELDS:
+            a, c = arrs[k][:n[k]], pinned[k][:n[k]]
+            assert np.array_equal(a.view(np.uint8), np.asarray(c).view(np.uint8)), k
+    finally:
+        pinned.clear()
+        for ptr in ptrs:
+            lib.dd_host_free(ptr)

@@ -302,3 +302,4 @@ def test_engine_bench_hook_runs():
     c = _host.bench_batch(48, reps=1, eager=True)
     assert a["errors"] == b["errors"] == c["errors"] == 0
     assert a["ll00"] == b["ll00"] == c["ll00"] and a["ll00"] < 0
+
