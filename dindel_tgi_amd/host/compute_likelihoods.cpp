@@ -439,6 +439,22 @@ bool WindowLikelihoods::hapIndelFilterCovered(size_t h, size_t r, int key) const
 bool WindowLikelihoods::coveredAt(size_t h, size_t r, int slot) const { return slot >= 0 && blk_->vcov[var_base(*blk_, w_, h, r) + slot] != 0; }
 bool WindowLikelihoods::filterCoveredAt(size_t h, size_t r, int slot) const { return slot >= 0 && blk_->fcov[var_base(*blk_, w_, h, r) + slot] != 0; }
 
+WindowLikelihoods::Rows WindowLikelihoods::rows(size_t h) const
+{
+    const BatchBlock &B = *blk_;
+    const int64_t p = pair(h, 0);
+    const int g = B.win_hap_off[w_] + int(h);
+    Rows R;
+    R.ll = B.ll.p + p; R.llOn = B.llOn.p + p; R.llOff = B.llOff.p + p; R.mLogBQ = B.mLogBQ.p + p;
+    R.offHap = B.offHap.p + p; R.offHapHMQ = B.offHapHMQ.p + p;
+    R.numIndels = B.numIndels.p + p; R.numMismatch = B.numMismatch.p + p; R.nBQT = B.nBQT.p + p; R.nmmBQT = B.nmmBQT.p + p;
+    R.nMMLeft = B.nMMLeft.p + p; R.nMMRight = B.nMMRight.p + p; R.firstBase = B.firstBase.p + p; R.lastBase = B.lastBase.p + p;
+    R.nv = B.hap_var_off[g + 1] - B.hap_var_off[g];
+    const int64_t vb = var_base(B, w_, h, 0);
+    R.vcov = B.vcov.p + vb; R.fcov = B.fcov.p + vb;
+    return R;
+}
+
 MLAlignment WindowLikelihoods::get(size_t h, size_t r) const
 {
     MLAlignment ml;

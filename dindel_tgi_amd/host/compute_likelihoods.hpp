@@ -68,6 +68,17 @@ public:
     int varSlot(size_t h, int key, bool snp) const;
     bool coveredAt(size_t h, size_t r, int slot) const;
     bool filterCoveredAt(size_t h, size_t r, int slot) const;
+    // One haplotype's scalars as plain rows indexed by read (x[r] == x(h, r)), and its covered flags: flag of variant slot s for read r
+    // is vcov[r * nv + s] (fcov likewise).  For loops over the reads; valid as long as the view is.
+    struct Rows {
+        const double *ll, *llOn, *llOff, *mLogBQ;
+        const uint8_t *offHap, *offHapHMQ, *vcov, *fcov;
+        const int16_t *numIndels, *numMismatch, *nBQT, *nmmBQT, *nMMLeft, *nMMRight, *firstBase, *lastBase;
+        int nv;
+        bool covered(size_t r, int slot) const { return slot >= 0 && vcov[r * size_t(nv) + size_t(slot)] != 0; }
+        bool filterCovered(size_t r, int slot) const { return slot >= 0 && fcov[r * size_t(nv) + size_t(slot)] != 0; }
+    };
+    Rows rows(size_t h) const;
     // the full record of one pair, built on demand (variant maps, align string, hpos).  If the batch was run without
     // alignments (setKeepAlignments(false)) the window is recomputed once through the engine and cached.
     MLAlignment get(size_t h, size_t r) const;

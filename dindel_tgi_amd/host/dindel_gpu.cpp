@@ -189,10 +189,10 @@ int main(int argc, char **argv)
         rsp.keepRecords = realignedBAM;
         unsigned hw = std::thread::hardware_concurrency();
         if (!hw) hw = 1;
-        // defaults measured on a 16-CPU share of an MI355X host (profiles/r02/n2_pipeline.md): per window the read selection and
-        // diploidGLF cost about the same CPU time, two engines keep the GPU busy while one of them packs
-        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
-        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(6u, std::max(1u, hw * 3 / 8))))));
+        // defaults measured on a 16-CPU share of an MI355X host (profiles/r02/n2_pipeline.md): per window the read selection costs
+        // ~0.35 ms of CPU, diploidGLF ~0.15 ms, packing ~0.05 ms; two engines keep the GPU busy while one of them packs
+        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(4u, std::max(1u, hw / 4))))));
+        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(8u, std::max(1u, hw / 2))))));
         // --devices 0,1,...: the engines are dealt out over these GPUs (batches are independent: no exchange between devices)
         std::vector<int> devices;
         {

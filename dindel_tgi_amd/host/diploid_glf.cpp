@@ -1,6 +1,11 @@
 // diploid_glf.cpp — see diploid_glf.hpp.  Line references are to the reference's DInDel.cpp.
 #include "diploid_glf.hpp"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <climits>
 #include <cmath>
 #include <iostream>
 #include <set>
@@ -24,9 +29,10 @@ void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read
         else { if (reads[r].isReverse()) strandOf[r] = 1; }
     }
     for (int h = 0; h < numHaps; h++) {
+        const WindowLikelihoods::Rows row = liks.rows(size_t(h));
         selReads.clear();                                                                    // :1951-1955
         for (size_t r = 0; r < reads.size(); r++)
-            if (!liks.offHapHMQ(size_t(h), r) && liks.numIndels(size_t(h), r) == 0) selReads.push_back(int(r));
+            if (!row.offHapHMQ[r] && row.numIndels[r] == 0) selReads.push_back(int(r));
         bool allCovered = true;
         for (It it = haps[size_t(h)].indels.begin(); it != haps[size_t(h)].indels.end(); ++it) {
             const AlignedVariant &av = it->second;
@@ -38,7 +44,7 @@ void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read
                 const int slot = liks.varSlot(size_t(h), it->first, false);
                 for (size_t k = 0; k < selReads.size(); k++) {
                     const int r = selReads[k];
-                    if (liks.filterCoveredAt(size_t(h), size_t(r), slot)) {                  // the device's test (:1989-2054)
+                    if (row.filterCovered(size_t(r), slot)) {                                // the device's test (:1989-2054)
                         cv->second[size_t(h + strandOf[size_t(r)] * numHaps)].push_back(r);
                         covered = true;
                     }
@@ -102,21 +108,53 @@ double getHaplotypePrior(const Haplotype &h1, const Haplotype &h2, int leftPos, 
     return ll;
 }
 
+namespace {
+// DINDEL_REDUCE_TIMING=1: seconds per section of diploidGLF, summed over all calls and threads, printed at exit (profiling aid)
+struct SectionClock {
+    static const int N = 8;
+    static std::atomic<long long> total[N];
+    static bool enabled() { static const bool on = getenv("DINDEL_REDUCE_TIMING") != NULL; return on; }
+    static void report()
+    {
+        static const char *name[N] = {"filterHaplotypes", "ll table", "variant tables", "haplotype priors", "pair sums", "dip.map lines", "position lines", ""};
+        for (int i = 0; i < 7; i++) fprintf(stderr, "reduce_timing: %-18s %.3f s\n", name[i], double(total[i].load()) * 1e-9);
+    }
+    std::chrono::steady_clock::time_point t;
+    bool on;
+    SectionClock() : on(enabled())
+    {
+        if (on) { static const int once = atexit(report); (void)once; t = std::chrono::steady_clock::now(); }
+    }
+    void mark(int section)
+    {
+        if (!on) return;
+        const std::chrono::steady_clock::time_point n = std::chrono::steady_clock::now();
+        total[section] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count();
+        t = n;
+    }
+};
+std::atomic<long long> SectionClock::total[SectionClock::N];
+}
+
 void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &reads, const WindowLikelihoods &liks, uint32_t candPos,
                 uint32_t leftPos, uint32_t rightPos, OutputData &glfData, int index, const std::string &tid,
                 const AlignedCandidates &candidateVariants, const DiploidParameters &params, const std::string &program)
 {
+    SectionClock clk;
     const size_t nh = haps.size(), nr = reads.size();
     std::vector<int> filtered(nh, 0);
     std::map<PAV, VariantCoverage> varCoverage;
     filterHaplotypes(haps, reads, liks, filtered, varCoverage, params.filterHaplotypes);        // :2941
+    clk.mark(0);
 
     std::vector<double> rl(nh * nr, 0.0);                                                    // :2943-2961
     {
-        size_t idx = 0;
-        for (size_t r = 0; r < nr; r++)
-            for (size_t h = 0; h < nh; h++) rl[idx++] = liks.ll(h, r);
+        for (size_t h = 0; h < nh; h++) {
+            const double *llh = liks.rows(h).ll;
+            for (size_t r = 0; r < nr; r++) rl[r * nh + h] = llh[r];
+        }
     }
+    clk.mark(1);
     const int VARSNP = 1, VARINDEL = 2;
     std::set<PAV> allVariants;
     std::map<int, std::set<PAV> > allVariantsByPos;
@@ -167,28 +205,45 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
     std::vector<double> mqOf(nr);                                                            // -10 log10(1 - mapQual), used thrice per read and variant position
     for (size_t r = 0; r < nr; r++) mqOf[r] = -10 * log10(1.0 - reads[r].mapQual);
 
+    clk.mark(2);
     std::vector<double> prior(nh * nh, 0.0), pairs_posterior(nh * nh, 0);                    // :3068-3075
     for (size_t h1 = 0; h1 < nh; h1++)
         for (size_t h2 = h1; h2 < nh; h2++) prior[h1 * nh + h2] = getHaplotypePrior(haps[h1], haps[h2], int(leftPos), candidateVariants, params);
 
+    clk.mark(3);
     std::vector<int> max_indel_pair(2, -1), max_noindel_pair(2, -1);
     double max_ll_indel = -HUGE_VAL, max_ll_noindel = -HUGE_VAL;
     // log(0.5) + addLogs(rl[r][h1], rl[r][h2]) per haplotype pair and read: the reference evaluates it here and again for every
-    // variant position (:3372-3376); the values are kept, the sums are redone in the reference's order each time
-    std::vector<long> pairSlot(nh * nh, -1);
-    long nPairs = 0;
-    for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) pairSlot[h1 * nh + h2] = nPairs++;
-    const bool keepTerms = size_t(nPairs) * nr <= (size_t(1) << 23);                          // at most 64 MB; beyond that they are recomputed
-    std::vector<double> pairTerm(keepTerms ? size_t(nPairs) * nr : 0), scratchTerm(keepTerms ? 0 : nr);
-    for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3083-3114
-        double ll = 0.0;
-        double *term = keepTerms ? &pairTerm[size_t(pairSlot[h1 * nh + h2]) * nr] : scratchTerm.data();
-        for (size_t r = 0; r < nr; r++) { term[r] = log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]); ll += term[r]; }
-        pairs_posterior[h1 * nh + h2] = ll + prior[h1 * nh + h2];
+    // variant position (:3372-3376); the values are kept (read-major: the pairs of one read side by side) and every sum is redone
+    // in the reference's order, read after read — all pairs at once, so that the additions of different pairs overlap instead of
+    // each pair waiting through its own chain of 200 dependent additions.
+    std::vector<size_t> pairH1, pairH2;                                                      // the pairs that take part, in the reference's loop order
+    for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) { pairH1.push_back(h1); pairH2.push_back(h2); }
+    const size_t nPairs = pairH1.size();
+    const bool keepTerms = nPairs * nr <= (size_t(1) << 23);                                  // at most 64 MB; beyond that they are recomputed
+    std::vector<double> pairTerm(keepTerms ? nPairs * nr : nPairs), pairSum(nPairs);
+    const double logHalf = log(0.5);
+    // sums[p] += term(p, r) for r = 0 .. nr-1, starting from what sums[] holds; stores the terms when they are kept
+    auto addTermsOfAllReads = [&](double *sums, bool compute) {
+        for (size_t r = 0; r < nr; r++) {
+            double *term = keepTerms ? &pairTerm[r * nPairs] : &pairTerm[0];
+            if (compute) {
+                const double *rlr = &rl[r * nh];
+                for (size_t p = 0; p < nPairs; p++) term[p] = logHalf + addLogs(rlr[pairH1[p]], rlr[pairH2[p]]);
+            }
+            for (size_t p = 0; p < nPairs; p++) sums[p] += term[p];
+        }
+    };
+    std::fill(pairSum.begin(), pairSum.end(), 0.0);                                          // :3083-3114
+    addTermsOfAllReads(pairSum.data(), true);
+    for (size_t p = 0; p < nPairs; p++) {
+        const size_t h1 = pairH1[p], h2 = pairH2[p];
+        pairs_posterior[h1 * nh + h2] = pairSum[p] + prior[h1 * nh + h2];
         const double pp = pairs_posterior[h1 * nh + h2];
         if (pp > max_ll_indel && (hap_num_candidate_indels[h1] > 0 || hap_num_candidate_indels[h2] > 0)) { max_ll_indel = pp; max_indel_pair[0] = int(h1); max_indel_pair[1] = int(h2); }
         if (pp > max_ll_noindel && (hap_num_candidate_indels[h1] == 0 && hap_num_candidate_indels[h2] == 0)) { max_ll_noindel = pp; max_noindel_pair[0] = int(h1); max_noindel_pair[1] = int(h2); }
     }
+    clk.mark(4);
     const double ll_ref = max_ll_noindel;
     const double qual = -10.0 * (ll_ref - addLogs(max_ll_indel, ll_ref)) / log(10.0);          // :3118
     if (!params.quiet) std::cout << "ll_ref: " << ll_ref << " max_ll_indel: " << max_ll_indel << " qual: " << qual << std::endl;
@@ -282,6 +337,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         }
     }
 
+    clk.mark(5);
     // ---- per variant position: genotype likelihoods over the haplotype pairs, coverage and QC sums (:3305-3660) ----
     for (PIt it = allVariantsByPos.begin(); it != allVariantsByPos.end(); ++it) {
         int has_variants_in_window = 0;
@@ -294,16 +350,16 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         const int posIdx = posToPosIdx[pos];
         double msq = 0.0;
         int n = 0;
-        typedef std::set<int> IntGenotype;
+        // the reference keys the genotype likelihoods by set<int>{v1, v2}; (smaller, larger) — a single-element set as (v, INT_MIN) —
+        // sorts the same way, and the map is walked in that order below
+        typedef std::pair<int, int> IntGenotype;
         std::map<IntGenotype, double> genLiks;
         std::map<std::pair<int, int>, double> pairPriorAt;
         double maxll = -HUGE_VAL;
         size_t hx1 = 0, hx2 = 0;
-        for (size_t h1 = 0; h1 < nh; h1++) if (filtered[h1] == 0) for (size_t h2 = h1; h2 < nh; h2++) if (filtered[h2] == 0) {     // :3347-3389
-            IntGenotype genotype;
+        for (size_t p = 0; p < nPairs; p++) {                                                // :3347-3389, the starting values
+            const size_t h1 = pairH1[p], h2 = pairH2[p];
             const int v1 = hapVar[h1 * size_t(numVarPos) + size_t(posIdx)], v2 = hapVar[h2 * size_t(numVarPos) + size_t(posIdx)];
-            genotype.insert(v1);
-            genotype.insert(v2);
             double logPriorPos;                                                              // a function of (v1, v2) alone at this position
             std::map<std::pair<int, int>, double>::const_iterator known = pairPriorAt.find(std::make_pair(v1, v2));
             if (known != pairPriorAt.end()) logPriorPos = known->second;
@@ -312,19 +368,22 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
                 const AlignedVariant av2 = v2 ? variants[size_t(v2)].second : AlignedVariant("*REF", -1);
                 logPriorPos = pairPriorAt[std::make_pair(v1, v2)] = getPairPrior(av1, av2, int(leftPos), candidateVariants, params);
             }
-            const double pr = prior[h1 * nh + h2] - logPriorPos;       // the site's prior taken out again: a likelihood
-            double ll = pr;
-            if (keepTerms) {
-                const double *term = &pairTerm[size_t(pairSlot[h1 * nh + h2]) * nr];
-                for (size_t r = 0; r < nr; r++) ll += term[r];
-            } else for (size_t r = 0; r < nr; r++) ll += log(0.5) + addLogs(rl[r * nh + h1], rl[r * nh + h2]);
+            pairSum[p] = prior[h1 * nh + h2] - logPriorPos;            // the site's prior taken out again: a likelihood
+        }
+        addTermsOfAllReads(pairSum.data(), !keepTerms);
+        for (size_t p = 0; p < nPairs; p++) {
+            const size_t h1 = pairH1[p], h2 = pairH2[p];
+            const int v1 = hapVar[h1 * size_t(numVarPos) + size_t(posIdx)], v2 = hapVar[h2 * size_t(numVarPos) + size_t(posIdx)];
+            const IntGenotype genotype(std::min(v1, v2), v1 == v2 ? INT_MIN : std::max(v1, v2));
+            const double ll = pairSum[p];
             std::map<IntGenotype, double>::iterator igit = genLiks.find(genotype);
-            if (igit == genLiks.end()) genLiks[genotype] = ll; else genLiks[genotype] = addLogs(genLiks[genotype], ll);
+            if (igit == genLiks.end()) genLiks[genotype] = ll; else igit->second = addLogs(igit->second, ll);
             if (ll > maxll) { maxll = ll; hx1 = h1; hx2 = h2; }
         }
+        const WindowLikelihoods::Rows row1 = liks.rows(hx1), row2 = liks.rows(hx2);
         int numUnmappedRealigned = 0;                                                        // :3395-3402
         for (size_t r = 0; r < nr; r++)
-            if (reads[r].isUnmapped() && (liks.offHap(hx1, r) == false || liks.offHap(hx2, r) == false)) numUnmappedRealigned++;
+            if (reads[r].isUnmapped() && (row1.offHap[r] == 0 || row2.offHap[r] == 0)) numUnmappedRealigned++;
         double allmsq = 0.0;                                                                 // :3492-3560
         int numMappedIndels = 0, nBQT = 0, nmmBQT = 0, nMMLeft = 0, nMMRight = 0, numOffBoth = 0;
         double mLogBQ = 0.0;
@@ -332,15 +391,17 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         for (size_t r = 0; r < numReadIdx; r++) {
             const double mq = mqOf[r];
             allmsq += (mq * mq);
-            if (liks.offHap(hx1, r) && liks.offHap(hx2, r)) numOffBoth++;
-            const size_t h = (liks.ll(hx1, r) >= liks.ll(hx2, r)) ? hx1 : hx2;                // the read's better haplotype of the pair
+            if (row1.offHap[r] && row2.offHap[r]) numOffBoth++;
+            const bool first = row1.ll[r] >= row2.ll[r];
+            const size_t h = first ? hx1 : hx2;                                              // the read's better haplotype of the pair
+            const WindowLikelihoods::Rows &row = first ? row1 : row2;
             bool nrt = false, nft = false, covered = false;
             numMappedIndels += liks.indelCount(h, r);                                        // liks[h][r].indels.size(), :3529
-            nBQT += liks.nBQT(h, r);
-            nmmBQT += liks.nmmBQT(h, r);
-            mLogBQ += liks.mLogBQ(h, r);
-            if (liks.nMMLeft(h, r) >= 2) nMMLeft++;
-            if (liks.nMMRight(h, r) >= 2) nMMRight++;
+            nBQT += row.nBQT[r];
+            nmmBQT += row.nmmBQT[r];
+            mLogBQ += row.mLogBQ[r];
+            if (row.nMMLeft[r] >= 2) nMMLeft++;
+            if (row.nMMRight[r] >= 2) nMMRight++;
             if (slotOf[h] == -2) {                                                           // :3536-3541
                 slotOf[h] = -1;
                 It hit = haps[h].indels.find(pos);
@@ -349,7 +410,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
                     else if (hit->second.isSNP()) slotOf[h] = liks.varSlot(h, pos, true);    // liks[h][r].hapSNPCovered[pos]
                 }
             }
-            covered = liks.coveredAt(h, r, slotOf[h]);
+            covered = row.covered(r, slotOf[h]);
             if (covered) {
                 if (reads[r].onReverseStrand) nrt = true; else nft = true;
                 const double mq2 = mqOf[r];
@@ -381,7 +442,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
         // :3600-3613
         first = 1;
         for (std::map<IntGenotype, double>::iterator git = genLiks.begin(); git != genLiks.end(); ++git) {
-            const int a1 = toVCFidx[*(git->first.begin())], a2 = toVCFidx[*(git->first.rbegin())];
+            const int a1 = toVCFidx[git->first.first], a2 = toVCFidx[git->first.second == INT_MIN ? git->first.first : git->first.second];
             o << ((first == 1) ? "" : ",") << a1 << "/" << a2 << ":" << git->second;
             first = 0;
         }
@@ -395,6 +456,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             glfData.output(dipPositionLine(glfData, d));
         }
     }
+    clk.mark(6);
 }
 
 } // namespace dindel

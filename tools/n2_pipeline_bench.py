@@ -101,7 +101,7 @@ except ImportError:
 base = [os.path.join(host, "dindel_gpu"), "--bamFile", bam, "--varFile", vf, "--hapFile", hf, "--outputFile", os.path.join(args.dir, "out"), "--timing"]
 if args.sweep:
     configs = [["--batchWindows", str(b), "--computeThreads", str(c), "--prepareThreads", str(p), "--reduceThreads", str(r), "--packThreads", str(k)] + f
-               for f in ([], ["--faster"]) for (b, c, p, r, k) in ((256, 1, 8, 4, 0), (256, 1, 6, 6, 4), (256, 2, 6, 6, 4), (256, 1, 8, 8, 4), (512, 1, 8, 8, 4))]
+               for f in ([], ["--faster"]) for (b, c, p, r, k) in ((256, 2, 6, 6, 4), (256, 2, 8, 4, 4), (256, 2, 10, 4, 4), (128, 2, 8, 4, 4), (256, 3, 8, 4, 2))]
 else:
     configs = [["--batchWindows", str(args.batch)] + (["--faster"] if args.faster else []) + args.extra.split()]
 for cfg in configs:
