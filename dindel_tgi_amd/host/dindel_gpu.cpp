@@ -274,6 +274,7 @@ int main(int argc, char **argv)
                     if (!toCompute.push(b)) break;
                 }
             } catch (std::string &s) { fail(s); }
+            catch (HaplotypeFixture::Error &e) { fail(e.message); }     // a malformed haplotype file ends the run, whichever window met it
             catch (std::exception &e) { fail(e.what()); }
         }));
 

@@ -338,6 +338,7 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
     }
 
     clk.mark(5);
+    std::vector<int> indelCountOf(nh * nr, -1);
     // ---- per variant position: genotype likelihoods over the haplotype pairs, coverage and QC sums (:3305-3660) ----
     for (PIt it = allVariantsByPos.begin(); it != allVariantsByPos.end(); ++it) {
         int has_variants_in_window = 0;
@@ -396,7 +397,9 @@ void diploidGLF(const std::vector<Haplotype> &haps, const std::vector<Read> &rea
             const size_t h = first ? hx1 : hx2;                                              // the read's better haplotype of the pair
             const WindowLikelihoods::Rows &row = first ? row1 : row2;
             bool nrt = false, nft = false, covered = false;
-            numMappedIndels += liks.indelCount(h, r);                                        // liks[h][r].indels.size(), :3529
+            int &known = indelCountOf[h * nr + r];                                           // liks[h][r].indels.size(), :3529: the same
+            if (known < 0) known = liks.indelCount(h, r);                                    // pair is asked for at every variant position
+            numMappedIndels += known;
             nBQT += row.nBQT[r];
             nmmBQT += row.nmmBQT[r];
             mLogBQ += row.mLogBQ[r];

@@ -634,6 +634,8 @@ int ddh_fixture_json(const char *path, const int *indices, int n, char *out, int
         return emit(os.str(), out, cap);
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    } catch (HaplotypeFixture::Error &e) {
+        return emit(std::string("{\"throw\":\"") + e.message + "\"}", out, cap);
     }
 }
 

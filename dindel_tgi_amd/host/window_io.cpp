@@ -1,6 +1,10 @@
 // window_io.cpp — see window_io.hpp.
 #include "window_io.hpp"
 #include <algorithm>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -218,58 +222,105 @@ void parseFixtureStretch(const char *p, const char *end, int lineNo, const std::
 }
 }
 
-HaplotypeFixture::HaplotypeFixture(const std::string &fileName)
+HaplotypeFixture::HaplotypeFixture(const std::string &fileName) : fileName_(fileName), text_(NULL), size_(0), mapped_(false)
 {
-    std::string text;
-    {
-        std::ifstream fin(fileName.c_str(), std::ios::binary);
-        if (!fin.is_open()) throw std::string("Cannot open haplotype file ").append(fileName);
-        std::ostringstream all;
-        all << fin.rdbuf();
-        text = all.str();
+    const int fd = open(fileName.c_str(), O_RDONLY);
+    if (fd < 0) throw std::string("Cannot open haplotype file ").append(fileName);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::string("Cannot open haplotype file ").append(fileName); }
+    size_ = size_t(st.st_size);
+    if (size_ > 0) {
+        void *m = mmap(NULL, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { text_ = static_cast<const char *>(m); mapped_ = true; }
+        else {                                                     // a file that cannot be mapped (a pipe): read it
+            char *buf = static_cast<char *>(malloc(size_));
+            size_t got = 0;
+            while (buf && got < size_) { const ssize_t k = read(fd, buf + got, size_ - got); if (k <= 0) break; got += size_t(k); }
+            if (!buf || got != size_) { free(buf); close(fd); throw std::string("Cannot read haplotype file ").append(fileName); }
+            text_ = buf;
+        }
     }
-    // cut at W lines into one stretch per worker; every stretch is parsed on its own and the windows are merged in file order
-    // (a later record of the same index replaces an earlier one, as a sequential read would)
+    close(fd);
+    // where the W records start, and how many lines lie in front of each: ranges of the file scanned side by side
+    struct Mark { size_t at; int linesBefore; };
     unsigned hw = std::thread::hardware_concurrency();
-    const size_t workers = text.size() < (1u << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
-    std::vector<size_t> cut(1, 0);
-    for (size_t k = 1; k < workers; k++) {
-        size_t at = text.size() / workers * k;
-        for (;;) {
-            at = text.find("\nW", at);
-            if (at == std::string::npos) break;
-            if (at + 2 < text.size() && (text[at + 2] == ' ' || text[at + 2] == '\t')) { at++; break; }
-            at++;
+    const size_t workers = size_ < (1u << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    std::vector<std::vector<Mark> > found(workers);
+    std::vector<int> linesIn(workers, 0);
+    auto scan = [&](size_t k) {
+        const size_t lo = size_ * k / workers, hi = size_ * (k + 1) / workers;
+        int lines = 0;
+        size_t p = lo;
+        if (p > 0 && text_[p - 1] != '\n') {                       // the line that straddles `lo` belongs to the range before
+            const void *nl = memchr(text_ + p, '\n', hi - p);
+            if (!nl) { linesIn[k] = 0; return; }
+            p = size_t(static_cast<const char *>(nl) - text_) + 1;
+            lines = 1;                                             // that newline is counted here: it lies in [lo, hi)
         }
-        if (at != std::string::npos && at > cut.back()) cut.push_back(at);
-    }
-    cut.push_back(text.size());
-    const size_t n = cut.size() - 1;
-    std::vector<std::vector<WindowHaplotypes> > parts(n);
-    std::vector<std::string> errors(n);
-    std::vector<int> lineBase(n, 0);
-    for (size_t k = 1; k < n; k++) lineBase[k] = lineBase[k - 1] + int(std::count(text.begin() + long(cut[k - 1]), text.begin() + long(cut[k]), '\n'));
-    std::vector<std::thread> pool;
-    auto work = [&](size_t k) {
-        try { parseFixtureStretch(text.data() + cut[k], text.data() + cut[k + 1], lineBase[k], fileName, parts[k]); }
-        catch (std::string &e) { errors[k] = e; }
+        while (p < hi) {
+            if (text_[p] == 'W' && p + 1 < size_ && (text_[p + 1] == ' ' || text_[p + 1] == '\t')) { Mark m = { p, lines }; found[k].push_back(m); }
+            const void *nl = memchr(text_ + p, '\n', hi - p);
+            if (!nl) break;
+            p = size_t(static_cast<const char *>(nl) - text_) + 1;
+            lines++;
+        }
+        linesIn[k] = lines;
     };
-    for (size_t k = 1; k < n; k++) pool.push_back(std::thread(work, k));
-    work(0);
-    for (size_t k = 0; k < pool.size(); k++) pool[k].join();
-    for (size_t k = 0; k < n; k++) if (!errors[k].empty()) throw errors[k];                  // the first one in file order
-    for (size_t k = 0; k < n; k++)
-        for (size_t i = 0; i < parts[k].size(); i++) {
-            WindowHaplotypes &slot = windows[parts[k][i].index];
-            slot.index = parts[k][i].index; slot.leftPos = parts[k][i].leftPos; slot.rightPos = parts[k][i].rightPos;
-            slot.haps.swap(parts[k][i].haps);
-        }
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < workers; k++) pool.push_back(std::thread(scan, k));
+        scan(0);
+        for (size_t k = 0; k < pool.size(); k++) pool[k].join();
+    }
+    std::vector<Mark> marks;
+    int base = 0;
+    for (size_t k = 0; k < workers; k++) {
+        for (size_t i = 0; i < found[k].size(); i++) { Mark m = { found[k][i].at, base + found[k][i].linesBefore }; marks.push_back(m); }
+        base += linesIn[k];
+    }
+    // records in front of the first window (comments; anything else is an error, reported now)
+    {
+        std::vector<WindowHaplotypes> none;
+        parseFixtureStretch(text_, text_ + (marks.empty() ? size_ : marks[0].at), 0, fileName_, none);
+    }
+    std::vector<WindowHaplotypes> head;
+    for (size_t i = 0; i < marks.size(); i++) {
+        const char *q = text_ + marks[i].at;
+        const char *lineEnd = static_cast<const char *>(memchr(q, '\n', size_ - marks[i].at));
+        if (!lineEnd) lineEnd = text_ + size_;
+        head.clear();
+        parseFixtureStretch(q, lineEnd, marks[i].linesBefore, fileName_, head);               // the W line itself: a malformed one is reported now
+        Entry e;
+        e.begin = marks[i].at; e.end = i + 1 < marks.size() ? marks[i + 1].at : size_; e.lineBase = marks[i].linesBefore; e.state = 0;
+        std::map<int, Entry>::iterator it = windows.find(head[0].index);
+        if (it == windows.end()) windows.insert(std::make_pair(head[0].index, e));
+        else { it->second.begin = e.begin; it->second.end = e.end; it->second.lineBase = e.lineBase; }     // the later record wins
+    }
+}
+
+HaplotypeFixture::~HaplotypeFixture()
+{
+    if (text_) { if (mapped_) munmap(const_cast<char *>(text_), size_); else free(const_cast<char *>(text_)); }
 }
 
 const WindowHaplotypes *HaplotypeFixture::find(int index) const
 {
-    std::map<int, WindowHaplotypes>::const_iterator it = windows.find(index);
-    return it == windows.end() ? NULL : &it->second;
+    std::map<int, Entry>::const_iterator it = windows.find(index);
+    if (it == windows.end()) return NULL;
+    const Entry &e = it->second;
+    std::lock_guard<std::mutex> lk(locks_[size_t(unsigned(index)) % 64]);
+    if (e.state == 0) {
+        std::vector<WindowHaplotypes> one;
+        try {
+            parseFixtureStretch(text_ + e.begin, text_ + e.end, e.lineBase, fileName_, one);
+            if (one.size() != 1) throw std::string("Cannot read window record of ").append(fileName_);
+            e.win.index = one[0].index; e.win.leftPos = one[0].leftPos; e.win.rightPos = one[0].rightPos;
+            e.win.haps.swap(one[0].haps);
+            e.state = 1;
+        } catch (std::string &msg) { e.error = msg; e.state = 2; }
+    }
+    if (e.state == 2) { Error err; err.message = e.error; throw err; }
+    return &e.win;
 }
 
 } // namespace dindel

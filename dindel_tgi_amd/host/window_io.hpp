@@ -7,6 +7,7 @@
 #define DINDEL_WINDOW_IO_HPP
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "dindel_types.hpp"
@@ -62,12 +63,23 @@ struct WindowHaplotypes {
     int index; uint32_t leftPos, rightPos;
     std::vector<Haplotype> haps;
 };
+// The file is indexed when it is opened (where each W record starts; a later record of an index replaces an earlier one) and a window's
+// records are parsed the first time it is asked for — by the thread that asks, so the workers that prepare windows side by side share
+// the parsing and a run does not wait for a 300-MB file to be read through before its first window.  A malformed record therefore
+// surfaces at find() of its window, as a HaplotypeFixture::Error (not a std::string: it is not one window's problem but the run's).
 class HaplotypeFixture {
 public:
-    explicit HaplotypeFixture(const std::string &fileName);
-    const WindowHaplotypes *find(int index) const;        // NULL: no haplotypes given for that window
+    struct Error { std::string message; };
+    explicit HaplotypeFixture(const std::string &fileName);   // throws std::string: cannot open; malformed records in front of the first W
+    ~HaplotypeFixture();
+    const WindowHaplotypes *find(int index) const;        // NULL: no haplotypes given for that window.  Thread-safe.
 private:
-    std::map<int, WindowHaplotypes> windows;
+    struct Entry { size_t begin, end; int lineBase; mutable int state; mutable WindowHaplotypes win; mutable std::string error; };
+    std::string fileName_;
+    const char *text_; size_t size_; bool mapped_;
+    std::map<int, Entry> windows;
+    mutable std::mutex locks_[64];
+    HaplotypeFixture(const HaplotypeFixture &); HaplotypeFixture &operator=(const HaplotypeFixture &);
 };
 
 } // namespace dindel

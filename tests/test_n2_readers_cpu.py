@@ -305,8 +305,14 @@ def test_haplotype_fixture_file_large_and_broken(lib, tmp_path):
     broken = list(lines)
     broken[bad_at] = broken[bad_at].rsplit(None, 1)[0] + " x7"
     open(path, "w").write("\n".join(broken) + "\n")
-    got = call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1)
+    assert call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1)[0] == want[1]        # windows are parsed when asked for: window 1 is fine
+    last_w = max(i for i in range(bad_at) if lines[i].startswith("W "))
+    got = call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(int(lines[last_w].split()[1])), 1)
     assert got == {"throw": "Cannot read variant record in line %d of %s" % (bad_at + 1, path)}
+    broken_w = list(lines)
+    broken_w[last_w] = "W 12 x 5"
+    open(path, "w").write("\n".join(broken_w) + "\n")
+    assert call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot read window record in line %d of %s" % (last_w + 1, path)}
     open(path, "w").write("H ACGT\n")
     assert call_json(lib.ddh_fixture_json, path.encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot read haplotype record in line 1 of %s" % path}
     assert call_json(lib.ddh_fixture_json, str(tmp_path / "nope").encode(), (C.c_int * 1)(1), 1) == {"throw": "Cannot open haplotype file %s" % (tmp_path / "nope")}

@@ -27,22 +27,29 @@ ap.add_argument("--faster", action="store_true")
 ap.add_argument("--keep", action="store_true", help="reuse the files of an earlier run with the same parameters")
 ap.add_argument("--sweep", action="store_true", help="run a list of batch sizes / thread counts instead of one configuration")
 ap.add_argument("--extra", default="", help="further driver options, blank-separated")
+ap.add_argument("--procs", type=int, default=min(16, os.cpu_count() or 1), help="processes writing the sample")
 args = ap.parse_args()
 os.makedirs(args.dir, exist_ok=True)
 bam, vf, hf = [os.path.join(args.dir, n) for n in ("reads.bam", "windows.txt", "haps.txt")]
 tag = os.path.join(args.dir, "params.json")
 want = dict(windows=args.windows, reads=args.reads)
-if not (args.keep and os.path.exists(tag) and json.load(open(tag)) == want):
-    t0 = time.time()
-    rng = np.random.default_rng(2026)
-    W, step, first = args.windows, 400, 5000
-    n_ref = first + W * step + 5000
-    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_ref)]
-    refs = ref.tobytes().decode()
-    windows, fixture, recs = [], [], []
-    rid = 0
-    for wi in range(1, W + 1):
-        left = first + (wi - 1) * step
+FIRST, STEP, BLOCK = 5000, 400, 60000
+
+
+def reference(W):
+    n_ref = FIRST + W * STEP + 5000
+    return np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(2026).integers(0, 4, n_ref)].tobytes().decode()
+
+
+def gen_chunk(job):
+    """Windows [w0, w1) (1-based): their window-file lines, fixture lines and reads — the reads already encoded as BAM records, sorted,
+    and compressed into BGZF blocks of BLOCK bytes that belong to this chunk alone (the parent only concatenates)."""
+    w0, w1, W, n_reads = job
+    refs = reference(W)
+    windows, fixture, blobs, pos, end = [], [], [], [], []
+    for wi in range(w0, w1):
+        rng = np.random.default_rng([2026, wi])
+        left = FIRST + (wi - 1) * STEP
         right = left + 120
         hap0 = refs[left:right + 1]
         offs = sorted(int(o) for o in rng.choice(np.arange(40, 81), 7, replace=False))
@@ -63,33 +70,115 @@ if not (args.keep and os.path.exists(tag) and json.load(open(tag)) == want):
         for h, o, _v, vline in haps:
             fixture += ["H " + h, vline, "V S %d *REF %d %d %d %d %d %d %d %d" % (o, o, o, o, o, o, o, o, o)] + refs_at(o)
         alt_h, alt_o, alt_v, _ = haps[int(rng.integers(0, 7))]
-        alt_full = refs[:left] + alt_h + refs[right + 1:]
+        alt_full = refs[left - 200:left] + alt_h + refs[right + 1:right + 400]      # the alternative chromosome around the window
         dlen = len(alt_h) - len(hap0)
-        for _ in range(args.reads):
+        mine = []
+        for k in range(n_reads):
             p = int(rng.integers(left - 60, left + 80))
             if rng.random() < 0.5:
-                seq, cigar, pos = refs[p:p + 100], "100M", p
+                seq, cigar, at = refs[p:p + 100], "100M", p
             else:
-                seq = alt_full[p:p + 100]
+                seq = alt_full[p - (left - 200):p - (left - 200) + 100]
                 cut = left + alt_o - p
-                pos = p
+                at = p
                 if cut <= 0:
-                    cigar, pos = "100M", p - dlen                     # right of the event: shifted on the reference
+                    cigar, at = "100M", p - dlen                       # right of the event: shifted on the reference
                     if dlen > 0 and cut > -dlen:
                         continue
                 elif dlen < 0:
                     cigar = "100M" if cut >= 100 else "%dM%dD%dM" % (cut, -dlen, 100 - cut)
                 else:
                     cigar = "100M" if cut + dlen >= 100 else "%dM%dI%dM" % (cut, dlen, 100 - cut - dlen)
-            recs.append(dict(qname="q%07d" % rid, flag=int(rng.integers(0, 2)) * 16, pos=pos, mapq=60, cigar=cigar, seq=seq, qual=[30] * 100,
+            mine.append(dict(qname="q%d_%d" % (wi, k), flag=int(rng.integers(0, 2)) * 16, pos=at, mapq=60, cigar=cigar, seq=seq, qual=[30] * 100,
                              mtid=-1, mpos=-1, isize=0, tags={}))
-            rid += 1
-    recs.sort(key=lambda r: r["pos"])
-    bw.write_bam(bam, "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:%d\n" % n_ref, [("20", n_ref)], [(0, r) for r in recs], block_bytes=60000)
-    open(vf, "w").write("\n".join(windows) + "\n")
-    open(hf, "w").write("\n".join(fixture) + "\n")
+        mine.sort(key=lambda r: r["pos"])
+        for r in mine:
+            b, e = bw.encode_record(0, r)
+            blobs.append(b); pos.append(r["pos"]); end.append(e)
+    u = b"".join(blobs)
+    lens = np.array([len(b) for b in blobs], dtype=np.int64)
+    comp, cstart = [], []
+    total = 0
+    for o in range(0, len(u), BLOCK):
+        blk = bw.bgzf_block(u[o:o + BLOCK])
+        cstart.append(total); total += len(blk); comp.append(blk)
+    return windows, fixture, b"".join(comp), np.array(cstart, dtype=np.int64), np.array(pos, dtype=np.int64), np.array(end, dtype=np.int64), lens
+
+
+def write_sample(W, n_reads, procs):
+    import multiprocessing as mp
+    import struct
+    n_ref = FIRST + W * STEP + 5000
+    per = max(1, (W + 4 * procs - 1) // (4 * procs))
+    jobs = [(w, min(w + per, W + 1), W, n_reads) for w in range(1, W + 1, per)]
+    with mp.Pool(procs) as pool:
+        parts = pool.map(gen_chunk, jobs)
+    header_text = "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:%d\n" % n_ref
+    hdr = b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", 1) + struct.pack("<I", 3) + b"20\0" + struct.pack("<I", n_ref)
+    out = [bw.bgzf_block(hdr)]
+    c0 = len(out[0])
+    beg_v, end_v, pos_all, end_all = [], [], [], []
+    starts = []                                   # compressed offset of each chunk
+    for (_w, _f, comp, cstart, pos, end, lens) in parts:
+        starts.append(c0)
+        c0 += len(comp)
+    eof_c = c0
+    for k, (_w, _f, comp, cstart, pos, end, lens) in enumerate(parts):
+        out.append(comp)
+        ub = np.concatenate([[0], np.cumsum(lens)[:-1]])           # uncompressed start of each record inside the chunk
+        ue = ub + lens
+        ulen = int(ue[-1]) if len(ue) else 0
+        nxt = starts[k + 1] if k + 1 < len(parts) else eof_c
+        voff = lambda uo: np.where(uo >= ulen, nxt << 16, ((starts[k] + cstart[np.minimum(uo // BLOCK, len(cstart) - 1)]) << 16) | (uo % BLOCK))
+        beg_v.append(voff(ub)); end_v.append(voff(ue)); pos_all.append(pos); end_all.append(end)
+    out.append(bw.bgzf_block(b""))
+    with open(bam, "wb") as f:
+        for o in out:
+            f.write(o)
+    beg_v, end_v, pos_all, end_all = [np.concatenate(x) for x in (beg_v, end_v, pos_all, end_all)]
+    # BAI: bins (reg2bin) with chunks = runs of records adjacent in the file, and the 16-kb linear index
+    e1 = end_all - 1
+    bins = np.zeros(len(pos_all), dtype=np.int64)
+    done = np.zeros(len(pos_all), dtype=bool)
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((pos_all >> shift) == (e1 >> shift))
+        bins[hit] = base + (pos_all[hit] >> shift)
+        done |= hit
+    order = np.lexsort((np.arange(len(bins)), bins))
+    sb, si = bins[order], order
+    brk = np.concatenate([[True], (sb[1:] != sb[:-1]) | (si[1:] != si[:-1] + 1)])
+    run_start = np.flatnonzero(brk)
+    run_end = np.concatenate([run_start[1:], [len(sb)]]) - 1
+    bai = bytearray(b"BAI\1" + struct.pack("<I", 1))
+    run_bins = sb[run_start]
+    ubins, first_run = np.unique(run_bins, return_index=True)
+    counts = np.diff(np.concatenate([first_run, [len(run_bins)]]))
+    bai += struct.pack("<I", len(ubins))
+    for b, f0, n in zip(ubins, first_run, counts):
+        bai += struct.pack("<II", int(b), int(n))
+        for j in range(f0, f0 + n):
+            bai += struct.pack("<QQ", int(beg_v[si[run_start[j]]]), int(end_v[si[run_end[j]]]))
+    n_intv = int(e1.max() >> 14) + 1
+    lin = np.full(n_intv, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(lin, pos_all >> 14, beg_v)
+    np.minimum.at(lin, e1 >> 14, beg_v)
+    last = 0
+    bai += struct.pack("<I", n_intv)
+    for w in range(n_intv):
+        if lin[w] != np.iinfo(np.int64).max:
+            last = int(lin[w])
+        bai += struct.pack("<Q", last)
+    open(bam + ".bai", "wb").write(bytes(bai))
+    open(vf, "w").write("\n".join(l for p in parts for l in p[0]) + "\n")
+    open(hf, "w").write("\n".join(l for p in parts for l in p[1]) + "\n")
+    return len(pos_all)
+
+
+if not (args.keep and os.path.exists(tag) and json.load(open(tag)) == want):
+    t0 = time.time()
+    n_written = write_sample(args.windows, args.reads, args.procs)
     json.dump(want, open(tag, "w"))
-    print("generated %d windows, %d reads in %.1f s" % (W, len(recs), time.time() - t0), flush=True)
+    print("generated %d windows, %d reads in %.1f s" % (args.windows, n_written, time.time() - t0), flush=True)
 host = os.path.join(ROOT, "dindel_tgi_amd", "host")
 subprocess.check_call(["make", "-s", "-C", host])
 env = dict(os.environ)
