@@ -586,6 +586,7 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     S.read_flags.resize(n_reads + 1); S.hap_var.resize(2 * n_var + 1); S.hap_var_flank.resize(3 * n_var + 1);
     if (with_mates) { S.read_mate_pos.resize(n_reads + 1); S.read_mate_len.resize(n_reads + 1); }
 
+    const std::chrono::steady_clock::time_point t_pass1 = std::chrono::steady_clock::now();
     // ---- pass 2: the bytes, windows in parallel ----
     ValueTable qtab, mqtab;
     std::atomic<int> overflow(0);
@@ -693,6 +694,9 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     dd_params P = to_abi(params);
     if (faster) P.mapUnmappedReads = 0;                 // ObservationModelS has no insert-size prior
     const std::chrono::steady_clock::time_point t_packed = std::chrono::steady_clock::now();
+    if (getenv("DD_TIMING"))
+        fprintf(stderr, "pack_timing: windows=%d pass1=%.2fms pass2+alloc=%.2fms\n", W, std::chrono::duration<double, std::milli>(t_pass1 - t_start).count(),
+                std::chrono::duration<double, std::milli>(t_packed - t_pass1).count());
     if (sz.n_pairs > 0) {
         const int rc = faster ? dd_compute_likelihoods_faster(&P, &Bt, &Rz, device_) : dd_compute_likelihoods(&P, &Bt, &Rz, device_);
         if (rc != DD_SUCCESS) throw std::string(faster ? "dd_compute_likelihoods_faster: " : "dd_compute_likelihoods: ") + dd_last_error();

@@ -268,6 +268,16 @@ int main(int argc, char **argv)
                             T.message = skippedMessage(s);
                             T.skipped = true;
                         }
+                        if (const char *dump = getenv("DINDEL_DUMP_READS")) {               // diagnostics: what the window hands to the likelihood step
+                            std::ofstream df((std::string(dump) + "." + std::to_string(T.index)).c_str());
+                            df.precision(17);
+                            for (size_t r = 0; r < T.reads.size(); r++) {
+                                const Read &R = T.reads[r];
+                                df << R.qname << " " << int32_t(R.pos) << " " << R.mapQual << " " << R.matePos << " " << R.mateLen << " " << R.isUnmapped() << " " << R.isPaired()
+                                   << " " << R.mateIsUnmapped() << " " << R.mateIsReverse() << " " << R.mateSameTid << " " << R.posStat.first << " "
+                                   << (R.library ? R.library->getMaxInsertSize() : -1) << " " << R.seq.seq << "\n";
+                            }
+                        }
                         fetcher.windowDone(T.skipped, T.fileLeftPos);                         // :1401-1408
                     }
                     t_prepare_of[size_t(pt)] += seconds_since(t0);

@@ -258,3 +258,110 @@ def test_driver_writes_realigned_bam(scene):
     # --faster has no realigned output, like the reference (`params.outputRealignedBAM && params.slower`)
     run_driver(scene, "raf", "--outputRealignedBAM", "--faster")
     assert not [f for f in os.listdir(str(scene["tmp"])) if f.startswith("raf.ra.")]
+
+
+def test_driver_with_library_file_matches_oracle_recomputation(tmp_path):
+    """--libFile switches the insert-size prior on (DInDel.cpp:4268-4272): read pairs, mapped reads with an unmapped mate and the
+    unmapped mates themselves go through getReads (mates found by name), the packing of mate position / length / library, and the
+    prior at the join.  The driver's qual and genotype quality equal a recomputation from the ORACLE's log-likelihoods of the reads
+    the window selected, library table included."""
+    from dindel_tgi_amd.batch import ReadRec, Window, pack
+    rng = np.random.default_rng(99)
+    r = list(rng.choice(list("ACGT"), 12000))
+    for i in range(3, len(r)):
+        if r[i] == r[i - 1] == r[i - 2] == r[i - 3]:
+            r[i] = "ACGT"[("ACGT".index(r[i]) + 1 + i % 3) % 4]
+    ref = "".join(r)
+    left = 6000
+    hap0 = ref[left:left + 121]
+    hap1 = hap0[:60] + hap0[62:]
+    alt = ref[:left + 60] + ref[left + 62:]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    recs = []
+
+    def cut(p, from_alt):                            # (pos, cigar, seq) of a 100-bp read starting at reference position p
+        if not from_alt:
+            return p, "100M", ref[p:p + 100]
+        c = left + 60 - p
+        if c <= 0:
+            return p, "100M", ref[p:p + 100]
+        return p, ("100M" if c >= 100 else "%dM2D%dM" % (c, 100 - c)), alt[p:p + 100]
+
+    for k in range(36):                              # proper pairs: first mate over the window, second one an insert size further right
+        from_alt = k % 2 == 0
+        p1 = int(rng.integers(left - 50, left + 55))
+        p2 = p1 + int(rng.normal(300, 15))
+        a, b = cut(p1, from_alt), cut(p2, False)
+        recs.append(dict(qname="p%02d" % k, flag=99, pos=a[0], mapq=60, cigar=a[1], seq=a[2], qual=[30] * 100, mtid=0, mpos=b[0], isize=p2 - p1 + 100, tags={"RG": "g1"}))
+        recs.append(dict(qname="p%02d" % k, flag=147, pos=b[0], mapq=60, cigar=b[1], seq=b[2], qual=[30] * 100, mtid=0, mpos=a[0], isize=-(p2 - p1 + 100), tags={"RG": "g1"}))
+    for k in range(8):                               # a mapped read over the window whose mate did not map: the mate sits at the same position
+        p1 = int(rng.integers(left - 40, left + 40))
+        a = cut(p1, k % 2 == 0)
+        rev = 16 if k % 4 < 2 else 0
+        mate_seq = "".join(comp[c] for c in reversed(ref[p1 + 20:p1 + 96])) if k % 3 else "".join(rng.choice(list("ACGT"), 76))
+        recs.append(dict(qname="u%02d" % k, flag=1 + 8 + 64 + rev, pos=a[0], mapq=50, cigar=a[1], seq=a[2], qual=[30] * 100, mtid=0, mpos=a[0], isize=0, tags={"RG": "g1"}))
+        recs.append(dict(qname="u%02d" % k, flag=1 + 4 + 128 + (0 if k % 2 else 16) + (32 if rev else 0), pos=a[0], mapq=0, cigar="", seq=mate_seq, qual=[30] * 76,
+                         mtid=0, mpos=a[0], isize=0, tags={"RG": "g1"}))
+    for k in range(10):                              # single-end reads
+        a = cut(int(rng.integers(left - 50, left + 55)), k % 2 == 0)
+        recs.append(dict(qname="s%02d" % k, flag=int(rng.choice([0, 16])), pos=a[0], mapq=60, cigar=a[1], seq=a[2], qual=[30] * 100, mtid=-1, mpos=-1, isize=0, tags={}))
+    recs.sort(key=lambda x: x["pos"])
+    bam = str(tmp_path / "pairs.bam")
+    bw.write_bam(bam, "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:12000\n@RG\tID:g1\tSM:s\tLB:libA\n", [("20", 12000)], [(0, x) for x in recs])
+    counts = np.round(1000 * np.exp(-0.5 * ((np.arange(700) - 300) / 20.0) ** 2)).astype(int)
+    libf = str(tmp_path / "libs.txt")
+    open(libf, "w").write("#LIB libA\n" + "".join("%d %d\n" % (i, c) for i, c in enumerate(counts)))
+    vf, hf = str(tmp_path / "w.txt"), str(tmp_path / "h.txt")
+    open(vf, "w").write("20 %d %d %d,-%s\n" % (left, left + 120, left + 60, hap0[60:62]))
+    open(hf, "w").write("\n".join(["W 1 %d %d" % (left, left + 120), "H " + hap0, "V I 60 *REF 60 60 60 60 60 60 60 60", "V S 60 *REF 60 60 60 60 60 60 60 60",
+                                   "H " + hap1, "V I 60 -%s 60 61 59 60 60 61 59 60" % hap0[60:62], "V S 60 *REF 60 60 60 60 60 60 60 60"]) + "\n")
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    scene = dict(tmp=tmp_path, bam=bam, vf=vf, hf=hf)
+    _path, rows = run_driver(scene, "lib", "--libFile", libf)
+    dm = [x for x in rows if x["analysis_type"] == "dip.map"]
+    assert len(dm) == 1 and dm[0]["msg"] == "ok", rows
+    # the reads the window selected, with the insert-size prior's inputs
+    lib = hostlib.load()
+    lib.ddh_get_reads_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_char_p, C.c_int]
+    out = C.create_string_buffer(1 << 24)
+    assert lib.ddh_get_reads_json(bam.encode(), libf.encode(), b"20", (C.c_int * 2)(left, left + 120), 1, (C.c_int * 4)(10000, 500, 20, 1), 0.99, out, len(out)) > 0
+    sel = json.loads(out.value.decode())[0]["reads"]
+    assert int(dm[0]["num_reads"]) == len(sel) and sum(x[5] for x in sel) >= 3 and int(dm[0]["num_unmapped_realigned"]) >= 0
+    by_key = {(x["qname"], bool(x["flag"] & 4), x["pos"]): x for x in recs}
+    # Library::calcProb (Library.hpp:78-128) of the histogram
+    mode = max(i for i, c in enumerate(counts) if c == counts.max())
+    maxins = min(25 * mode, len(counts))
+    probs = np.maximum(counts[:maxins] / float(counts[:maxins].sum()), 1e-10)
+    srt = np.sort(probs)
+    acc, p95 = 0.0, float(srt[-1])
+    for x in range(len(srt) - 1, 0, -1):
+        acc += srt[x]
+        if acc > 0.95:
+            p95 = float(srt[x])
+            break
+    reads = []
+    for q, pos, mq, mate_pos, mate_len, unmapped, seq, pstat in sel:
+        x = by_key[(q, bool(unmapped), pos)]
+        reads.append(ReadRec(seq, [1.0 - 10 ** -3.0] * len(seq), mq, int(pstat), unmapped=bool(unmapped), paired=bool(x["flag"] & 1), mate_unmapped=bool(x["flag"] & 8),
+                             mate_reverse=bool(x["flag"] & 32), mate_same_tid=x["mtid"] == 0, mate_pos=mate_pos, mate_len=mate_len if x["flag"] & 1 else -1, lib=0))
+    p = capi.params_cli_defaults()
+    p.mapUnmappedReads = 1
+    want = _oracle.batch(p, pack([Window(left, [hap0, hap1], reads)], libraries=[(probs, p95)]))
+    R = len(reads)
+    ll = [want["ll"][h * R:(h + 1) * R] for h in range(2)]
+    pp = {}
+    for h1, h2 in ((0, 0), (0, 1), (1, 1)):
+        s = 0.0
+        for k in range(R):
+            s += math.log(0.5) + add_logs(ll[h1][k], ll[h2][k])
+        pp[(h1, h2)] = s + (0.0 if (h1, h2) == (0, 0) else math.log(1.0 / 10000.0))
+    best = max(((0, 1), (1, 1)), key=lambda k: pp[k])
+    qual = -10.0 * (pp[(0, 0)] - add_logs(pp[best], pp[(0, 0)])) / math.log(10.0)
+    alt_best = max(v for k, v in pp.items() if k != best)
+    genoqual = -10.0 * (alt_best - add_logs(pp[best], alt_best)) / math.log(10.0)
+    assert best == (0, 1)
+    assert dm[0]["qual"] == "%g" % qual and dm[0]["glf"] == "0/1:%g" % genoqual, (dm[0]["qual"], qual, dm[0]["glf"], genoqual)
+    # and the prior matters: without the library table the same reads give another number
+    plain = capi.params_cli_defaults()
+    ll0 = _oracle.batch(plain, pack([Window(left, [hap0, hap1], reads)]))["ll"]
+    assert not np.array_equal(np.asarray(ll0), np.asarray(want["ll"]))
