@@ -60,6 +60,21 @@ std::string join(const std::vector<std::string> &v, const char *sep)
 }
 
 // FileUtils.FileWithHeader opened for reading: header labels and one dict per line
+// FileUtils.FileWithHeader: a space-separated table with a header line; readline() gives the row as label -> cell (FileUtils.py:107-125:
+// nothing at end of file or at an empty line).  The row is kept as the cells in column order with the labels' positions looked up once
+// (the script builds a dict per line: 29 cells x 480,000 lines for a 60,000-window run).
+class TableRow {
+public:
+    const std::string &operator[](const char *key) const
+    {
+        std::map<std::string, size_t>::const_iterator it = index->find(key);
+        if (it == index->end()) throw std::string("KeyError: ").append(key);
+        return cells[it->second];
+    }
+    std::vector<std::string> cells;
+    const std::map<std::string, size_t> *index;
+};
+
 class TableReader {
 public:
     explicit TableReader(const std::string &fname) : f(fname.c_str()), name(fname)
@@ -68,31 +83,38 @@ public:
         std::string header;
         std::getline(f, header);
         labels = split(rstrip(header, " \t\r\n\v\f"), ' ');               // FileUtils.py:55,57
+        for (size_t i = 0; i < labels.size(); i++) index[labels[i]] = i;    // a repeated label: the last column wins, as in the dict
     }
-    bool readline(std::map<std::string, std::string> &res)                // FileUtils.py:107-125: {} at end of file or at an empty line
+    bool readline(TableRow &res)
     {
-        std::string rline;
         if (!std::getline(f, rline)) return false;
-        const std::vector<std::string> line = split(rstrip(rstrip(rline, "\n"), " "), ' ');
-        if (line.size() == 1 && line[0].empty()) return false;
-        if (line.size() != labels.size())
+        size_t end = rline.size();
+        while (end > 0 && rline[end - 1] == '\n') end--;                   // rstrip("\n").rstrip(" ")
+        while (end > 0 && rline[end - 1] == ' ') end--;
+        res.index = &index;
+        size_t n = 0, start = 0;
+        for (;;) {                                                         // str.split(' '): every single blank separates
+            size_t sp = rline.find(' ', start);
+            if (sp == std::string::npos || sp >= end) sp = end;
+            if (n == res.cells.size()) res.cells.push_back(std::string());
+            res.cells[n++].assign(rline, start, sp - start);
+            if (sp >= end) break;
+            start = sp + 1;
+        }
+        res.cells.resize(n);
+        if (n == 1 && res.cells[0].empty()) return false;
+        if (n != labels.size())
             throw std::string("Line in file ").append(name).append(" does not have the correct number of labels");
-        res.clear();
-        for (size_t i = 0; i < labels.size(); i++) res[labels[i]] = line[i];
         return true;
     }
 private:
     std::ifstream f;
-    std::string name;
+    std::string name, rline;
     std::vector<std::string> labels;
+    std::map<std::string, size_t> index;
 };
 
-const std::string &col(const std::map<std::string, std::string> &dat, const char *key)
-{
-    std::map<std::string, std::string>::const_iterator it = dat.find(key);
-    if (it == dat.end()) throw std::string("KeyError: ").append(key);
-    return it->second;
-}
+const std::string &col(const TableRow &dat, const char *key) { return dat[key]; }
 
 } // namespace
 
@@ -242,7 +264,7 @@ int processDiploidGLFFile(const std::string &glfFile, CallsByChrom &variants, In
     (void)maxHPLen;          // :219 calls getVCFString without maxHPLen: the hp filter always uses the default 10, whatever --maxHPLen says
     TableReader fglf(glfFile);
     int numSkipped = 0;
-    std::map<std::string, std::string> dat;
+    TableRow dat;
     while (fglf.readline(dat)) {
         if (col(dat, "msg") != "ok") { numSkipped++; continue; }           // :182-184
         if (col(dat, "analysis_type") != "dip.map") continue;             // :186
