@@ -217,7 +217,8 @@ int dd_partition_windows(const dd_batch *b, int n_parts, int32_t *bounds);
 void dd_release_cache(void);
 /* Page-locked host memory for the arrays of dd_batch / dd_result: with it the H2D / D2H copies of dd_compute_likelihoods run
  * at full link speed and truly overlap the kernels (pageable memory is staged by the runtime).  Optional: any host pointer
- * works.  dd_host_alloc returns NULL when there is no device or the allocation fails. */
+ * works.  dd_host_alloc returns NULL when there is no device or the allocation fails.  Output arrays of dd_compute_likelihoods that
+ * lie in such memory are written by the kernels directly (see dd_last_direct_outputs). */
 void *dd_host_alloc(size_t bytes);
 void dd_host_free(void *p);
 
