@@ -157,6 +157,16 @@ def test_pinned_outputs_are_written_in_place(lib, n_windows, faster):
         for k, _typ in capi.RESULT_FIELDS:
             a, c = arrs[k][:n[k]], pinned[k][:n[k]]
             assert np.array_equal(a.view(np.uint8), np.asarray(c).view(np.uint8)), k
+        # the same through the several-devices entry point (two window blocks, each on its own host thread, both writing into the
+        # one pinned set of arrays)
+        for k, _typ in capi.RESULT_FIELDS:
+            pinned[k][...] = 0x33 if np.dtype(RESULT_DTYPES[k]).kind != "f" else -2.5
+        devs = (C.c_int * 2)(0, 0)
+        multi = lib.dd_compute_likelihoods_faster_multi if faster else lib.dd_compute_likelihoods_multi
+        assert multi(C.byref(p), C.byref(b), C.byref(res2), devs, 2) == 0, capi.last_error()
+        for k, _typ in capi.RESULT_FIELDS:
+            a, c = arrs[k][:n[k]], pinned[k][:n[k]]
+            assert np.array_equal(a.view(np.uint8), np.asarray(c).view(np.uint8)), ("multi", k)
     finally:
         pinned.clear()
         for ptr in ptrs:
