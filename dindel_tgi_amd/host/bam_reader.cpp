@@ -63,6 +63,7 @@ bool BgzfReader::loadBlock(int64_t address)
     comp.resize(size_t(clen) + 8);
     if (fread(comp.data(), 1, comp.size(), f) != comp.size()) return false;
     const uint32_t isize = le32(comp.data() + clen + 4);
+    if (isize > 65536u) throw std::string("corrupt BGZF block");      // a BGZF block holds at most 64 KiB
     CachedBlock &C = cache[cacheNext];
     C.address = -1;                                       // not valid while it is being filled (an exception leaves it so)
     if (C.data.size() < (isize ? isize : 1)) C.data.resize(isize ? isize : 1);
