@@ -248,6 +248,35 @@ def alloc_result(pb: PackedBatch, fill=None):
     return arrs, res
 
 
+def alloc_result_pinned(pb: PackedBatch, fill=0x55):
+    """Like alloc_result, with every array in page-locked host memory (dd_host_alloc): the kernels then write the outputs in place.
+    Returns (arrays, dd_result, release); call release() when the arrays are no longer used."""
+    import ctypes as C
+    lib = capi.load()
+    n = result_lengths(pb)
+    arrs, ptrs = {}, []
+    res = capi.dd_result()
+    for k, typ in capi.RESULT_FIELDS:
+        dt = np.dtype(RESULT_DTYPES[k])
+        cnt = max(n[k], 1)
+        ptr = lib.dd_host_alloc(cnt * dt.itemsize)
+        if not ptr:
+            for q in ptrs:
+                lib.dd_host_free(q)
+            raise MemoryError("dd_host_alloc failed")
+        ptrs.append(ptr)
+        arrs[k] = np.frombuffer((C.c_char * (cnt * dt.itemsize)).from_address(ptr), dtype=dt)
+        if fill is not None:
+            arrs[k].view(np.uint8)[...] = fill
+        setattr(res, k, C.cast(C.c_void_p(ptr), typ))
+
+    def release():
+        arrs.clear()
+        while ptrs:
+            lib.dd_host_free(ptrs.pop())
+    return arrs, res, release
+
+
 def pair_slices(pb: PackedBatch, w: int):
     """Index helpers for window w: (pair0, H, R, hpos0, SL, read_seq_off0)."""
     a = pb.a

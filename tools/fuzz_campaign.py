@@ -73,6 +73,26 @@ while time.time() < t_end:
         assert_same(got, _oracle.batch(p, pb, nthreads=16), pb)
         gotf = run_faster(lib, p, pb)
         assert_same_faster(gotf, _oracle.batch(p, pb, nthreads=16, faster=True), pb)
+        if rnd % 3 == 1:            # the same calls with the outputs in page-locked memory (written by the kernels in place)
+            import ctypes as C
+            from dindel_tgi_amd.batch import alloc_result_pinned, result_lengths
+            n = result_lengths(pb)
+            hb = pb.ctypes_batch()
+            for call, ref in ((lib.dd_compute_likelihoods, got), (lib.dd_compute_likelihoods_faster, gotf)):
+                arrs, res, release = alloc_result_pinned(pb)
+                try:
+                    assert call(C.byref(p), C.byref(hb), C.byref(res), 0) == 0, capi.last_error()
+                    assert lib.dd_last_direct_outputs() >= 10, "outputs were not written in place"
+                    okp = ref["status"][:pb.n_pairs] == 0
+                    assert np.array_equal(arrs["status"][:pb.n_pairs], ref["status"][:pb.n_pairs]), "pinned status"
+                    assert np.array_equal(arrs["onHap"][:pb.n_reads], ref["onHap"][:pb.n_reads]), "pinned onHap"
+                    for k in ("ll", "llOn", "llOff", "offHap", "offHapHMQ", "firstBase", "lastBase", "numIndels", "numMismatch", "nBQT", "nmmBQT", "nMMLeft", "nMMRight"):
+                        assert np.array_equal(arrs[k][:pb.n_pairs][okp].view(np.uint8), ref[k][:pb.n_pairs][okp].view(np.uint8)), ("pinned", k)
+                    if okp.all():
+                        for k in ("hpos", "var_covered", "var_fcov", "mLogBQ"):
+                            assert np.array_equal(arrs[k][:n[k]].view(np.uint8), ref[k][:n[k]].view(np.uint8)), ("pinned", k)
+                finally:
+                    release()
         if rnd % 4 == 0:            # device-pointer entry points (one batch-wide plan) against the host path (length classes)
             from dindel_tgi_amd.device import DeviceBatch
             import torch
