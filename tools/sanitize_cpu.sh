@@ -6,9 +6,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 gcc -O1 -g -fPIC -std=c99 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared \
     -o /tmp/libdd_oracle_asan.so "$ROOT/oracle/dd_oracle.c" -lm
 g++ -O1 -g -fPIC -std=c++11 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o /tmp/libdindel_host_asan.so \
-    "$ROOT"/dindel_tgi_amd/host/{compute_likelihoods,genotype,cigar,host_capi}.cpp -L"$ROOT/dindel_tgi_amd/csrc" -ldindel_hmm \
-    -Wl,-rpath,"$ROOT/dindel_tgi_amd/csrc"
+    "$ROOT"/dindel_tgi_amd/host/{compute_likelihoods,genotype,cigar,host_capi,glf_to_vcf,bam_reader,window_io,get_reads,diploid_glf,realigned_bam}.cpp \
+    -L"$ROOT/dindel_tgi_amd/csrc" -ldindel_hmm -lz -pthread -Wl,-rpath,"$ROOT/dindel_tgi_amd/csrc"
 cd "$ROOT"
-LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 DD_ORACLE_LIB=/tmp/libdd_oracle_asan.so \
+# libstdc++ is preloaded too: python itself does not link it, and ASan's __cxa_throw interceptor must find the real one at start-up
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 DD_ORACLE_LIB=/tmp/libdd_oracle_asan.so \
     DD_HOST_LIB=/tmp/libdindel_host_asan.so python -m pytest tests/test_oracle_kat.py tests/test_oracle_fast_cpu.py tests/test_host_adapter_cpu.py \
-    tests/test_genotype_n1.py tests/test_cigar_cpu.py -q -m "not gpu" -p no:cacheprovider
+    tests/test_genotype_n1.py tests/test_cigar_cpu.py tests/test_n2_readers_cpu.py tests/test_glf_vcf_cpu.py -q -m "not gpu" -p no:cacheprovider
