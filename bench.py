@@ -15,7 +15,7 @@ windows/s on: `windows_per_s_incl_copies` (dd_compute_likelihoods with host poin
 and `windows_per_s_end_to_end` (dindel::LikelihoodEngine::computeLikelihoodsBatch on the reference's own
 C++ objects: pack + H2D + kernels + D2H + per-window status scan, records delivered as lazy views), with
 the split and the eager-record rate under `end_to_end`, and `window_loop`: the batched window loop of the diploid analysis (BAM ->
-read selection -> kernels -> diploidGLF -> .glf.txt, host/dindel_gpu) on a synthetic 20,000-window sample the leg writes itself.
+read selection -> kernels -> diploidGLF -> .glf.txt, host/dindel_gpu) on a synthetic 40,000-window sample the leg writes itself.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000] [--total-windows T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -105,7 +105,7 @@ def cpu_baseline(pb, params, seconds_target=15.0, faster=False):
                 windows_per_s=n_win / dt)
 
 
-def window_loop_leg(faster, windows=20000):
+def window_loop_leg(faster, windows=40000):
     """The batched window loop (host/dindel_gpu: BAM -> read selection -> GPU likelihoods -> diploidGLF -> .glf.txt) on a synthetic
     sample written by tools/n2_pipeline_bench.py, as a child process; the driver's own clock (set-up to last line written)."""
     import shutil
