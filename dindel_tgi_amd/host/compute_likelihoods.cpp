@@ -535,31 +535,58 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     for (int w = 0; w < W; w++) if (jobs[w].liks) any_eager = true;
     B.has_hpos = keepAlignments_ || any_eager;
 
-    // ---- pack (CSR), pass 1: sizes and offsets (serial, O(haplotypes + reads)) ----
+    // ---- pack (CSR), pass 1: sizes and offsets.  Per window in parallel (its haplotypes and reads are scattered objects: the pass is
+    // cache misses), one serial prefix sum over the windows in between ----
     const bool with_mates = params.mapUnmappedReads && !faster;
-    B.win_hap_off.assign(1, 0); B.win_read_off.assign(1, 0); B.hap_var_off.assign(1, 0); B.read_seq_off.assign(1, 0);
-    S.hap_seq_off.assign(1, 0);
-    std::vector<int32_t> lib_off(1, 0);
-    std::vector<double> lib_prob, lib_p95;
-    std::map<const Library *, int> lib_index;
-    int64_t n_hap_bases = 0, n_read_bases = 0;
-    if (with_mates) S.read_lib.clear();
-    for (int w = 0; w < W; w++) {
+    const unsigned nthr1 = pick_threads(hostThreads_, W);
+    std::vector<int64_t> whb(size_t(W) + 1, 0), wrb(size_t(W) + 1, 0), wvar(size_t(W) + 1, 0);       // per window: haplotype bases, read bases, variants
+    B.win_hap_off.assign(size_t(W) + 1, 0); B.win_read_off.assign(size_t(W) + 1, 0);
+    std::atomic<int> bad_read(0);
+    parallel_windows(W, nthr1, 16, [&](int w) {
         WindowJob &J = jobs[w];
         J.error.clear();
-        for (size_t h = 0; h < J.haps->size(); h++) {
-            const Haplotype &H = (*J.haps)[h];
-            n_hap_bases += int64_t(H.seq.size());
-            S.hap_seq_off.push_back(int32_t(n_hap_bases));
-            B.hap_var_off.push_back(B.hap_var_off.back() + int32_t(H.indels.size() + H.snps.size()));
-        }
-        B.win_hap_off.push_back(B.win_hap_off.back() + int32_t(J.haps->size()));
+        int64_t hb = 0, rb = 0, nv = 0;
+        for (size_t h = 0; h < J.haps->size(); h++) { const Haplotype &H = (*J.haps)[h]; hb += int64_t(H.seq.size()); nv += int64_t(H.indels.size() + H.snps.size()); }
         for (size_t r = 0; r < J.reads->size(); r++) {
             const Read &R = (*J.reads)[r];
-            if (R.qual.size() != R.size()) throw std::string("Read: qual and seq differ in length");
-            n_read_bases += int64_t(R.size());
-            B.read_seq_off.push_back(int32_t(n_read_bases));
-            if (with_mates) {
+            if (R.qual.size() != R.size()) bad_read.store(1);
+            rb += int64_t(R.size());
+        }
+        whb[size_t(w) + 1] = hb; wrb[size_t(w) + 1] = rb; wvar[size_t(w) + 1] = nv;
+        B.win_hap_off[size_t(w) + 1] = int32_t(J.haps->size()); B.win_read_off[size_t(w) + 1] = int32_t(J.reads->size());
+    });
+    if (bad_read.load()) throw std::string("Read: qual and seq differ in length");
+    for (int w = 0; w < W; w++) {
+        whb[size_t(w) + 1] += whb[size_t(w)]; wrb[size_t(w) + 1] += wrb[size_t(w)]; wvar[size_t(w) + 1] += wvar[size_t(w)];
+        B.win_hap_off[size_t(w) + 1] += B.win_hap_off[size_t(w)]; B.win_read_off[size_t(w) + 1] += B.win_read_off[size_t(w)];
+        if (whb[size_t(w) + 1] > 0x7fffffffLL || wrb[size_t(w) + 1] > 0x7fffffffLL)
+            throw std::string("batch too large: more than 2^31 haplotype or read bases (split the windows over several calls)");
+    }
+    const int64_t n_hap_bases = whb[size_t(W)], n_read_bases = wrb[size_t(W)];
+    B.hap_var_off.resize(size_t(B.win_hap_off[size_t(W)]) + 1); S.hap_seq_off.resize(size_t(B.win_hap_off[size_t(W)]) + 1);
+    B.read_seq_off.resize(size_t(B.win_read_off[size_t(W)]) + 1);
+    B.hap_var_off[0] = 0; S.hap_seq_off[0] = 0; B.read_seq_off[0] = 0;
+    parallel_windows(W, nthr1, 16, [&](int w) {
+        const WindowJob &J = jobs[w];
+        int64_t hb = whb[size_t(w)], rb = wrb[size_t(w)], nv = wvar[size_t(w)];
+        const size_t g0 = size_t(B.win_hap_off[size_t(w)]), q0 = size_t(B.win_read_off[size_t(w)]);
+        for (size_t h = 0; h < J.haps->size(); h++) {
+            const Haplotype &H = (*J.haps)[h];
+            hb += int64_t(H.seq.size()); nv += int64_t(H.indels.size() + H.snps.size());
+            S.hap_seq_off[g0 + h + 1] = int32_t(hb);
+            B.hap_var_off[g0 + h + 1] = int32_t(nv);
+        }
+        for (size_t r = 0; r < J.reads->size(); r++) { rb += int64_t((*J.reads)[r].size()); B.read_seq_off[q0 + r + 1] = int32_t(rb); }
+    });
+    std::vector<int32_t> lib_off(1, 0);
+    std::vector<double> lib_prob, lib_p95;
+    if (with_mates) {                                    // libraries in order of first appearance (serial: the order defines the indices)
+        std::map<const Library *, int> lib_index;
+        S.read_lib.clear();
+        for (int w = 0; w < W; w++) {
+            const WindowJob &J = jobs[w];
+            for (size_t r = 0; r < J.reads->size(); r++) {
+                const Read &R = (*J.reads)[r];
                 int li = 0;
                 if (R.isPaired()) {                      // the reference dereferences the library of paired reads only (:279-289)
                     if (!R.library) throw std::string("Cannot find library: ");            // Read.hpp:176
@@ -576,9 +603,6 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
                 S.read_lib.push_back(uint8_t(li));
             }
         }
-        B.win_read_off.push_back(B.win_read_off.back() + int32_t(J.reads->size()));
-        if (n_hap_bases > 0x7fffffffLL || n_read_bases > 0x7fffffffLL)
-            throw std::string("batch too large: more than 2^31 haplotype or read bases (split the windows over several calls)");
     }
     const size_t n_haps = size_t(B.win_hap_off[W]), n_reads = size_t(B.win_read_off[W]), n_var = size_t(B.hap_var_off[n_haps]);
     S.win_hap_start.resize(size_t(W)); S.hap_seq.resize(size_t(n_hap_bases) + 1); S.read_seq.reserve(size_t(n_read_bases) + 1);
