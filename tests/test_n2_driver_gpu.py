@@ -185,6 +185,24 @@ def test_driver_batching_is_exact_and_vcf_follows(scene):
     assert all(l[6] == "PASS" for l in body)
 
 
+def test_driver_skips_windows_over_the_hap_read_product(scene):
+    """--maxHapReadProd (DInDel.cpp:395-399): a window with more haplotypes x reads than the limit is skipped with the reference's message
+    and the others are called as before."""
+    full = open(run_driver(scene, "hp_full")[0]).read().split("\n")
+    n_reads = {int(l.split(" ")[1]): int(l.split(" ")[11]) for l in full[1:] if " dip.map " in l}
+    assert len(set(n_reads.values())) > 1
+    limit = 2 * min(n_reads.values()) + 1                      # two haplotypes per window: the thinnest window stays under the limit
+    path, rows = run_driver(scene, "hp", "--maxHapReadProd", str(limit))
+    by = {}
+    for r in rows:
+        by.setdefault(int(r["index"]), []).append(r)
+    for wi, n in n_reads.items():
+        if 2 * n > limit:
+            assert [r["msg"] for r in by[wi]] == ["error_skipped_numhap_times_numread>%d" % limit], wi
+        else:
+            assert [l for l in full[1:] if l.split(" ")[1:2] == [str(wi)]] == [l for l in open(path).read().split("\n")[1:] if l.split(" ")[1:2] == [str(wi)]]
+
+
 def test_driver_faster_model_runs_the_same_loop(scene):
     _path, rows = run_driver(scene, "f", "--faster")
     dm = [r for r in rows if r["analysis_type"] == "dip.map"]
