@@ -65,6 +65,7 @@ struct Batch {
     std::vector<WindowTask> tasks;
     std::vector<WindowJob> jobs;
     std::vector<size_t> jobOf;
+    std::vector<int> toRelease;          // windows of the batch's previous use whose parsed haplotypes are no longer needed
 };
 typedef std::unique_ptr<Batch> BatchPtr;
 
@@ -250,6 +251,8 @@ int main(int argc, char **argv)
                 BatchPtr b;
                 while (toPrepare.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                    for (size_t i = 0; i < b->toRelease.size(); i++) fixture.release(b->toRelease[i]);
+                    b->toRelease.clear();
                     std::string oldTid;
                     for (size_t i = 0; i < b->tasks.size(); i++) {
                         WindowTask &T = b->tasks[i];
@@ -389,6 +392,9 @@ int main(int argc, char **argv)
                         nWindows++;
                     }
                     glfOutput.flush();
+                    // the haplotypes of these windows can go: noted here, dropped by the prepare worker that takes the batch next
+                    // (side by side with the others, not in this thread's serial part)
+                    for (size_t i = 0; i < B.tasks.size(); i++) if (B.tasks[i].haps) { B.toRelease.push_back(B.tasks[i].index); B.tasks[i].haps = NULL; }
                     B.jobs.clear();                                               // drops the batch's views: its result block can be reused
                     B.jobOf.clear();
                     recycled.give(b);
@@ -454,8 +460,14 @@ int main(int argc, char **argv)
         if (!has("quiet")) std::cout << "windows: " << nWindows << " skipped: " << nSkipped << " -> " << glfFile << std::endl;
         if (has("timing")) {
             const double wall = seconds_since(t_start);
+            long peakKb = 0;                                                      // VmHWM of /proc/self/status
+            {
+                std::ifstream st("/proc/self/status");
+                std::string line;
+                while (std::getline(st, line)) if (line.compare(0, 6, "VmHWM:") == 0) peakKb = atol(line.c_str() + 6);
+            }
             std::cout << "timing: wall=" << wall << " setup=" << t_setup << " prepare_threads=" << prepareThreads << " prepare=" << t_prepare << " compute_threads=" << computeThreads << " compute=" << t_compute << " (pack=" << t_pack
-                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce_threads=" << reduceThreads << " reduce=" << t_reduce << " (work=" << t_reduce_work << " summed over the threads)" << " windows_per_s=" << double(nWindows) / wall << std::endl;
+                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce_threads=" << reduceThreads << " reduce=" << t_reduce << " (work=" << t_reduce_work << " summed over the threads)" << " peak_rss_mb=" << peakKb / 1024 << " windows_per_s=" << double(nWindows) / wall << std::endl;
         }
     } catch (std::string &s) {
         std::cerr << "Exception: " << s << std::endl;

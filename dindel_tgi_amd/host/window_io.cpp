@@ -323,4 +323,13 @@ const WindowHaplotypes *HaplotypeFixture::find(int index) const
     return &e.win;
 }
 
+void HaplotypeFixture::release(int index) const
+{
+    std::map<int, Entry>::const_iterator it = windows.find(index);
+    if (it == windows.end()) return;
+    const Entry &e = it->second;
+    std::lock_guard<std::mutex> lk(locks_[size_t(unsigned(index)) % 64]);
+    if (e.state == 1) { std::vector<Haplotype>().swap(e.win.haps); e.state = 0; }
+}
+
 } // namespace dindel

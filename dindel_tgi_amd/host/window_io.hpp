@@ -73,6 +73,9 @@ public:
     explicit HaplotypeFixture(const std::string &fileName);   // throws std::string: cannot open; malformed records in front of the first W
     ~HaplotypeFixture();
     const WindowHaplotypes *find(int index) const;        // NULL: no haplotypes given for that window.  Thread-safe.
+    // the caller is done with what find(index) returned: the parsed records are dropped (a later find() parses them again), so that a
+    // long run holds the windows in flight only
+    void release(int index) const;
 private:
     struct Entry { size_t begin, end; int lineBase; mutable int state; mutable WindowHaplotypes win; mutable std::string error; };
     std::string fileName_;
