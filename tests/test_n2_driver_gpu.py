@@ -383,3 +383,23 @@ def test_driver_with_library_file_matches_oracle_recomputation(tmp_path):
     plain = capi.params_cli_defaults()
     ll0 = _oracle.batch(plain, pack([Window(left, [hap0, hap1], reads)]))["ll"]
     assert not np.array_equal(np.asarray(ll0), np.asarray(want["ll"]))
+
+
+def test_driver_ragged_sample_is_batching_invariant(tmp_path):
+    """Windows of 90-330 bp with 2-12 haplotypes (several lane tilings of the kernel in one batch), 20-400 reads of 60-150 bp with mixed
+    base and mapping qualities (tools/n2_pipeline_bench.py --ragged): the .glf.txt does not depend on how the windows are cut into
+    batches or on the thread counts, for either model."""
+    import sys
+    root = os.path.dirname(HOST.rstrip("/")).rsplit("/", 1)[0]
+    d = str(tmp_path / "ragged")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "n2_pipeline_bench.py"), "--windows", "400", "--ragged", "--dir", d, "--procs", "2"],
+                       capture_output=True, text=True)
+    assert "generated 400 windows" in r.stdout, r.stdout + r.stderr
+    scene = dict(tmp=tmp_path, bam=d + "/reads.bam", vf=d + "/windows.txt", hf=d + "/haps.txt")
+    for model in ([], ["--faster"]):
+        a = open(run_driver(scene, "rg_a", *model)[0]).read()
+        b = open(run_driver(scene, "rg_b", "--batchWindows", "1", "--prepareThreads", "1", "--computeThreads", "1", "--reduceThreads", "1", *model)[0]).read()
+        c = open(run_driver(scene, "rg_c", "--batchWindows", "23", "--prepareThreads", "3", "--computeThreads", "3", "--reduceThreads", "5", *model)[0]).read()
+        assert a == b == c
+        rows = [l.split(" ") for l in a.split("\n")[1:] if l]
+        assert len({l[1] for l in rows if l[2] == "dip.map"}) > 350                       # nearly every window is called

@@ -27,12 +27,13 @@ ap.add_argument("--faster", action="store_true")
 ap.add_argument("--keep", action="store_true", help="reuse the files of an earlier run with the same parameters")
 ap.add_argument("--sweep", action="store_true", help="run a list of batch sizes / thread counts instead of one configuration")
 ap.add_argument("--extra", default="", help="further driver options, blank-separated")
+ap.add_argument("--ragged", action="store_true", help="windows of 90-330 bp, 2-12 haplotypes, 20-400 reads of 60-150 bp each (default: uniform 120 bp / 8 / 200 x 100 bp)")
 ap.add_argument("--procs", type=int, default=min(16, os.cpu_count() or 1), help="processes writing the sample")
 args = ap.parse_args()
 os.makedirs(args.dir, exist_ok=True)
 bam, vf, hf = [os.path.join(args.dir, n) for n in ("reads.bam", "windows.txt", "haps.txt")]
 tag = os.path.join(args.dir, "params.json")
-want = dict(windows=args.windows, reads=args.reads)
+want = dict(windows=args.windows, reads=args.reads, ragged=bool(args.ragged))
 FIRST, STEP, BLOCK = 5000, 400, 60000
 
 
@@ -44,15 +45,18 @@ def reference(W):
 def gen_chunk(job):
     """Windows [w0, w1) (1-based): their window-file lines, fixture lines and reads — the reads already encoded as BAM records, sorted,
     and compressed into BGZF blocks of BLOCK bytes that belong to this chunk alone (the parent only concatenates)."""
-    w0, w1, W, n_reads = job
+    w0, w1, W, n_reads, ragged = job
     refs = reference(W)
     windows, fixture, blobs, pos, end = [], [], [], [], []
     for wi in range(w0, w1):
         rng = np.random.default_rng([2026, wi])
         left = FIRST + (wi - 1) * STEP
-        right = left + 120
+        width = int(rng.integers(90, 331)) if ragged else 120
+        n_var = int(rng.integers(1, 12)) if ragged else 7
+        n_here = int(rng.integers(20, 401)) if ragged else n_reads
+        right = left + width
         hap0 = refs[left:right + 1]
-        offs = sorted(int(o) for o in rng.choice(np.arange(40, 81), 7, replace=False))
+        offs = sorted(int(o) for o in rng.choice(np.arange(width // 3, 2 * width // 3 + 1), n_var, replace=False))
         haps, cands = [], []
         for o in offs:
             n = int(rng.integers(1, 4))
@@ -69,28 +73,30 @@ def gen_chunk(job):
         fixture += ["H " + hap0] + refs_at(-1)
         for h, o, _v, vline in haps:
             fixture += ["H " + h, vline, "V S %d *REF %d %d %d %d %d %d %d %d" % (o, o, o, o, o, o, o, o, o)] + refs_at(o)
-        alt_h, alt_o, alt_v, _ = haps[int(rng.integers(0, 7))]
+        alt_h, alt_o, alt_v, _ = haps[int(rng.integers(0, n_var))]
         alt_full = refs[left - 200:left] + alt_h + refs[right + 1:right + 400]      # the alternative chromosome around the window
         dlen = len(alt_h) - len(hap0)
         mine = []
-        for k in range(n_reads):
-            p = int(rng.integers(left - 60, left + 80))
+        for k in range(n_here):
+            L = int(rng.integers(60, 151)) if ragged else 100
+            p = int(rng.integers(left - 60, left + width - 40))
             if rng.random() < 0.5:
-                seq, cigar, at = refs[p:p + 100], "100M", p
+                seq, cigar, at = refs[p:p + L], "%dM" % L, p
             else:
-                seq = alt_full[p - (left - 200):p - (left - 200) + 100]
+                seq = alt_full[p - (left - 200):p - (left - 200) + L]
                 cut = left + alt_o - p
                 at = p
                 if cut <= 0:
-                    cigar, at = "100M", p - dlen                       # right of the event: shifted on the reference
+                    cigar, at = "%dM" % L, p - dlen                    # right of the event: shifted on the reference
                     if dlen > 0 and cut > -dlen:
                         continue
                 elif dlen < 0:
-                    cigar = "100M" if cut >= 100 else "%dM%dD%dM" % (cut, -dlen, 100 - cut)
+                    cigar = "%dM" % L if cut >= L else "%dM%dD%dM" % (cut, -dlen, L - cut)
                 else:
-                    cigar = "100M" if cut + dlen >= 100 else "%dM%dI%dM" % (cut, dlen, 100 - cut - dlen)
-            mine.append(dict(qname="q%d_%d" % (wi, k), flag=int(rng.integers(0, 2)) * 16, pos=at, mapq=60, cigar=cigar, seq=seq, qual=[30] * 100,
-                             mtid=-1, mpos=-1, isize=0, tags={}))
+                    cigar = "%dM" % L if cut + dlen >= L else "%dM%dI%dM" % (cut, dlen, L - cut - dlen)
+            quals = [int(q) for q in rng.integers(10, 41, L)] if ragged else [30] * L
+            mine.append(dict(qname="q%d_%d" % (wi, k), flag=int(rng.integers(0, 2)) * 16, pos=at, mapq=int(rng.choice([20, 40, 60])) if ragged else 60, cigar=cigar, seq=seq,
+                             qual=quals, mtid=-1, mpos=-1, isize=0, tags={}))
         mine.sort(key=lambda r: r["pos"])
         for r in mine:
             b, e = bw.encode_record(0, r)
@@ -105,12 +111,12 @@ def gen_chunk(job):
     return windows, fixture, b"".join(comp), np.array(cstart, dtype=np.int64), np.array(pos, dtype=np.int64), np.array(end, dtype=np.int64), lens
 
 
-def write_sample(W, n_reads, procs):
+def write_sample(W, n_reads, procs, ragged=False):
     import multiprocessing as mp
     import struct
     n_ref = FIRST + W * STEP + 5000
     per = max(1, (W + 4 * procs - 1) // (4 * procs))
-    jobs = [(w, min(w + per, W + 1), W, n_reads) for w in range(1, W + 1, per)]
+    jobs = [(w, min(w + per, W + 1), W, n_reads, ragged) for w in range(1, W + 1, per)]
     with mp.Pool(procs) as pool:
         parts = pool.map(gen_chunk, jobs)
     header_text = "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:20\tLN:%d\n" % n_ref
@@ -176,7 +182,7 @@ def write_sample(W, n_reads, procs):
 
 if not (args.keep and os.path.exists(tag) and json.load(open(tag)) == want):
     t0 = time.time()
-    n_written = write_sample(args.windows, args.reads, args.procs)
+    n_written = write_sample(args.windows, args.reads, args.procs, args.ragged)
     json.dump(want, open(tag, "w"))
     print("generated %d windows, %d reads in %.1f s" % (args.windows, n_written, time.time() - t0), flush=True)
 host = os.path.join(ROOT, "dindel_tgi_amd", "host")
