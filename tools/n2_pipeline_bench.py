@@ -27,6 +27,7 @@ ap.add_argument("--faster", action="store_true")
 ap.add_argument("--keep", action="store_true", help="reuse the files of an earlier run with the same parameters")
 ap.add_argument("--sweep", action="store_true", help="run a list of batch sizes / thread counts instead of one configuration")
 ap.add_argument("--extra", default="", help="further driver options, blank-separated")
+ap.add_argument("--vcf", action="store_true", help="afterwards: dindel_glf2vcf on the .glf.txt, and the calls against the variants the reads were drawn with")
 ap.add_argument("--ragged", action="store_true", help="windows of 90-330 bp, 2-12 haplotypes, 20-400 reads of 60-150 bp each (default: uniform 120 bp / 8 / 200 x 100 bp)")
 ap.add_argument("--procs", type=int, default=min(16, os.cpu_count() or 1), help="processes writing the sample")
 args = ap.parse_args()
@@ -47,7 +48,7 @@ def gen_chunk(job):
     and compressed into BGZF blocks of BLOCK bytes that belong to this chunk alone (the parent only concatenates)."""
     w0, w1, W, n_reads, ragged = job
     refs = reference(W)
-    windows, fixture, blobs, pos, end = [], [], [], [], []
+    windows, fixture, blobs, pos, end, truth = [], [], [], [], [], []
     for wi in range(w0, w1):
         rng = np.random.default_rng([2026, wi])
         left = FIRST + (wi - 1) * STEP
@@ -74,6 +75,7 @@ def gen_chunk(job):
         for h, o, _v, vline in haps:
             fixture += ["H " + h, vline, "V S %d *REF %d %d %d %d %d %d %d %d" % (o, o, o, o, o, o, o, o, o)] + refs_at(o)
         alt_h, alt_o, alt_v, _ = haps[int(rng.integers(0, n_var))]
+        truth.append("%d %d %d %s" % (wi, left + alt_o, len(alt_h) - len(hap0), alt_v))      # the heterozygous variant of this window
         alt_full = refs[left - 200:left] + alt_h + refs[right + 1:right + 400]      # the alternative chromosome around the window
         dlen = len(alt_h) - len(hap0)
         mine = []
@@ -108,7 +110,7 @@ def gen_chunk(job):
     for o in range(0, len(u), BLOCK):
         blk = bw.bgzf_block(u[o:o + BLOCK])
         cstart.append(total); total += len(blk); comp.append(blk)
-    return windows, fixture, b"".join(comp), np.array(cstart, dtype=np.int64), np.array(pos, dtype=np.int64), np.array(end, dtype=np.int64), lens
+    return windows, fixture, b"".join(comp), np.array(cstart, dtype=np.int64), np.array(pos, dtype=np.int64), np.array(end, dtype=np.int64), lens, truth
 
 
 def write_sample(W, n_reads, procs, ragged=False):
@@ -125,11 +127,11 @@ def write_sample(W, n_reads, procs, ragged=False):
     c0 = len(out[0])
     beg_v, end_v, pos_all, end_all = [], [], [], []
     starts = []                                   # compressed offset of each chunk
-    for (_w, _f, comp, cstart, pos, end, lens) in parts:
+    for (_w, _f, comp, cstart, pos, end, lens, _t) in parts:
         starts.append(c0)
         c0 += len(comp)
     eof_c = c0
-    for k, (_w, _f, comp, cstart, pos, end, lens) in enumerate(parts):
+    for k, (_w, _f, comp, cstart, pos, end, lens, _t) in enumerate(parts):
         out.append(comp)
         ub = np.concatenate([[0], np.cumsum(lens)[:-1]])           # uncompressed start of each record inside the chunk
         ue = ub + lens
@@ -177,6 +179,13 @@ def write_sample(W, n_reads, procs, ragged=False):
     open(bam + ".bai", "wb").write(bytes(bai))
     open(vf, "w").write("\n".join(l for p in parts for l in p[0]) + "\n")
     open(hf, "w").write("\n".join(l for p in parts for l in p[1]) + "\n")
+    open(os.path.join(args.dir, "truth.txt"), "w").write("\n".join(l for p in parts for l in p[7]) + "\n")
+    refs = reference(W)                                          # FASTA + .fai for the glf -> VCF step
+    with open(os.path.join(args.dir, "ref.fa"), "w") as f:
+        f.write(">20\n")
+        off = f.tell()
+        f.write("\n".join(refs[i:i + 60] for i in range(0, len(refs), 60)) + "\n")
+    open(os.path.join(args.dir, "ref.fa.fai"), "w").write("20\t%d\t%d\t60\t61\n" % (len(refs), off))
     return len(pos_all)
 
 
@@ -213,3 +222,26 @@ for cfg in configs:
         timing = [l for l in out.stdout.split("\n") if l.startswith("timing:")]
         print(json.dumps(dict(rep=rep, windows=args.windows, options=" ".join(cfg), seconds=round(dt, 3), windows_per_s=round(args.windows / dt, 1),
                               dip_map_lines=calls, skipped=skipped, driver=timing[-1] if timing else None)), flush=True)
+
+if args.vcf:
+    lst = os.path.join(args.dir, "glf_files.txt")
+    open(lst, "w").write(os.path.join(args.dir, "out.glf.txt") + "\n")
+    vcf = os.path.join(args.dir, "calls.vcf")
+    t0 = time.time()
+    subprocess.check_call([os.path.join(host, "dindel_glf2vcf"), "-i", lst, "-o", vcf, "-r", os.path.join(args.dir, "ref.fa"), "-s", "SAMPLE"], stdout=subprocess.DEVNULL)
+    dt = time.time() - t0
+    calls = {}
+    for l in open(vcf):
+        if l.startswith("#"):
+            continue
+        c = l.rstrip("\n").split("\t")
+        calls.setdefault(int(c[1]), []).append((len(c[4]) - len(c[3]), c[9].split(":")[0], c[6]))
+    truth = [l.split() for l in open(os.path.join(args.dir, "truth.txt")) if l.strip()]
+    found = het = 0
+    for _wi, pos, dlen, _v in truth:
+        hit = [x for x in calls.get(int(pos), []) if x[0] == int(dlen)]
+        found += bool(hit)
+        het += bool([x for x in hit if x[1] == "0/1"])
+    n_calls = sum(len(v) for v in calls.values())
+    print(json.dumps(dict(step="glf2vcf", seconds=round(dt, 3), vcf_records=n_calls, windows=len(truth), true_variant_called=found, called_heterozygous=het,
+                          other_records=n_calls - found)), flush=True)
