@@ -403,3 +403,15 @@ def test_driver_ragged_sample_is_batching_invariant(tmp_path):
         assert a == b == c
         rows = [l.split(" ") for l in a.split("\n")[1:] if l]
         assert len({l[1] for l in rows if l[2] == "dip.map"}) > 350                       # nearly every window is called
+
+
+def test_window_loop_calls_the_simulated_variants(tmp_path):
+    """BAM -> .glf.txt -> VCF on a sample whose reads were drawn from the reference and from ONE of each window's candidate haplotypes
+    (tools/n2_pipeline_bench.py --vcf): nearly every window's VCF record is that variant, at its position, heterozygous."""
+    import sys
+    root = os.path.dirname(HOST.rstrip("/")).rsplit("/", 1)[0]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "n2_pipeline_bench.py"), "--windows", "500", "--dir", str(tmp_path / "s"), "--procs", "2", "--vcf"],
+                       capture_output=True, text=True)
+    last = [json.loads(l) for l in r.stdout.split("\n") if l.startswith("{")][-1]
+    assert last["step"] == "glf2vcf" and last["windows"] == 500, r.stdout + r.stderr
+    assert last["true_variant_called"] >= 485 and last["called_heterozygous"] == last["true_variant_called"] and last["vcf_records"] <= 510
