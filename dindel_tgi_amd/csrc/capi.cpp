@@ -1236,7 +1236,17 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
 #define UP(field, n) if ((rc = dev.upload(&db.field, b->field, (size_t)(n)))) return rc
     UP(win_hap_off, W + 1); UP(win_read_off, W + 1); UP(win_hap_start, W);
     UP(hap_seq_off, sz.n_haps + 1); UP(hap_seq, sz.hap_bases);
-    UP(read_seq_off, sz.n_reads + 1); UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases);
+    UP(read_seq_off, sz.n_reads + 1);
+    // The two big inputs (one byte per read base each).  Large batches: only reserved here — each window block's share is copied
+    // on the block's own stream right in front of its kernels, so all but the first block's transfer hides behind the kernels of
+    // the block before.
+    const bool late_reads = !staged && sz.read_bases > 0;
+    char *d_read_seq = nullptr; uint8_t *d_read_qidx = nullptr;
+    if (late_reads) {
+        if ((rc = dev.alloc(&d_read_seq, (size_t)sz.read_bases))) return rc;
+        if ((rc = dev.alloc(&d_read_qidx, (size_t)sz.read_bases))) return rc;
+        db.read_seq = d_read_seq; db.read_qidx = d_read_qidx;
+    } else { UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases); }
     UP(read_mqidx, sz.n_reads); UP(read_start, sz.n_reads); UP(read_flags, sz.n_reads);
 #undef UP
     if (b->hap_var_off) {
@@ -1344,6 +1354,11 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     for (int c = 0; c < n_chunks; c++) {
         const int w0 = cw[c], w1 = cw[c + 1];
         const int g0 = b->win_hap_off[w0], g1 = b->win_hap_off[w1], q0 = b->win_read_off[w0], q1 = b->win_read_off[w1];
+        if (late_reads && q1 > q0) {
+            const size_t s0 = (size_t)b->read_seq_off[q0], sn = (size_t)b->read_seq_off[q1] - s0;
+            HIP_TRY(hipMemcpyAsync(d_read_seq + s0, b->read_seq + s0, sn, hipMemcpyHostToDevice, streams.s[c & 1]));
+            HIP_TRY(hipMemcpyAsync(d_read_qidx + s0, b->read_qidx + s0, sn, hipMemcpyHostToDevice, streams.s[c & 1]));
+        }
         if (single_class) {
             rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1);
             if (rc) return rc;
