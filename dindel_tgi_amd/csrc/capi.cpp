@@ -1179,18 +1179,20 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     struct ReadClass { int lo, hi, max_len; };
     std::vector<ReadClass> rcls;
     {
-        int lo = 1;
-        for (int bound : kReadBounds) {
-            int mx = 0;
-            for (int w = 0; w < W; w++) {
-                if (win_skip[(size_t)w]) continue;
-                for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
-                    const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
-                    if (len >= lo && len <= bound && len > mx) mx = len;
-                }
+        int mx[2] = {0, 0};                                  // longest read of each class, one pass over the reads
+        for (int w = 0; w < W; w++) {
+            if (win_skip[(size_t)w]) continue;
+            for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
+                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+                if (len < 1) continue;
+                const int c = len <= kReadBounds[0] ? 0 : 1;
+                if (len <= kReadBounds[c] && len > mx[c]) mx[c] = len;
             }
-            if (mx) rcls.push_back({lo, bound, mx});
-            lo = bound + 1;
+        }
+        int lo = 1;
+        for (int c = 0; c < 2; c++) {
+            if (mx[c]) rcls.push_back({lo, kReadBounds[c], mx[c]});
+            lo = kReadBounds[c] + 1;
         }
         if (rcls.empty()) rcls.push_back({1, kReadBounds[0], 1});       // every window skipped: the marking launch still runs
         if (getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k") && !rcls.empty()) {
