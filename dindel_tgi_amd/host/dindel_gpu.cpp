@@ -155,6 +155,18 @@ double seconds_since(const std::chrono::steady_clock::time_point &t0)
 int main(int argc, char **argv)
 {
     std::map<std::string, std::string> opt;
+    for (int i = 1; i < argc; i++) if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) {
+        std::cout <<
+            "dindel_gpu: the --analysis indels --doDiploid window loop with the likelihood step on the GPU\n"
+            "  required: --bamFile F --varFile F --hapFile F --outputFile PREFIX          (writes PREFIX.glf.txt)\n"
+            "  model:    [--faster] [--libFile F] [--filterHaplotypes] [--outputRealignedBAM] [--varFileIsOneBased]\n"
+            "            [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]\n"
+            "            [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X] [--maxHapReadProd N]\n"
+            "  running:  [--batchWindows N] [--device D | --devices D0,D1,...] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N]\n"
+            "            [--quiet] [--timing] [--prepareOnly]\n"
+            "  files:    --varFile: the reference's window file; --hapFile: W / H / V / A records (host/window_io.hpp)\n";
+        return 0;
+    }
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
