@@ -21,7 +21,7 @@ c_f64p = C.POINTER(C.c_double)
 DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 2 * 256 + 64
 DD_READ_UNMAPPED, DD_READ_PAIRED, DD_READ_MATE_UNMAPPED, DD_READ_MATE_REVERSE, DD_READ_MATE_SAME_TID = 1, 2, 4, 8, 16
 
-ABI_VERSION = 10           # DD_ABI_VERSION of include/dindel_hmm.h
+ABI_VERSION = 11           # DD_ABI_VERSION of include/dindel_hmm.h
 DD_HPOS_INS, DD_HPOS_LO, DD_HPOS_RO, DD_HPOS_INS_KEY0 = -1, -3, -4, -16
 
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
@@ -112,7 +112,7 @@ class dd_device_result(C.Structure):
 
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets", "dd_screen_windows",
-           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_compute_likelihoods_multi", "dd_compute_likelihoods_faster_multi", "dd_partition_windows", "dd_launch_device_faster", "dd_release_cache", "dd_host_alloc", "dd_host_free", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
+           "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_compute_likelihoods_multi", "dd_compute_likelihoods_faster_multi", "dd_partition_windows", "dd_launch_device_faster", "dd_release_cache", "dd_reserve_cache", "dd_host_alloc", "dd_host_free", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
            "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_last_direct_outputs", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 

@@ -311,6 +311,15 @@ void dd_release_cache(void)
     g_ctx.c.release();
 }
 
+int dd_reserve_cache(int device, size_t device_bytes, size_t pinned_bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DD_ERR_NO_DEVICE, "no HIP device: the likelihood path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(DD_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return g_ctx.c.reserve(device, device_bytes, pinned_bytes);
+}
+
 void *dd_host_alloc(size_t bytes)
 {
     void *p = nullptr;

@@ -496,6 +496,13 @@ void LikelihoodEngine::computeLikelihoodsFaster(const std::vector<Haplotype> &ha
     if (!jobs[0].error.empty()) throw jobs[0].error;
 }
 
+void LikelihoodEngine::warmUp(size_t pairs)
+{
+    // per pair: ~25 input bytes (a read of 100 bases is shared by its window's haplotypes) and ~270 result bytes if everything is staged
+    const size_t bytes = pairs * 300 + (size_t(32) << 20);
+    if (dd_reserve_cache(device_, bytes, bytes <= (size_t(64) << 20) ? bytes : 0) != DD_SUCCESS) throw std::string("dd_reserve_cache: ") + dd_last_error();
+}
+
 void LikelihoodEngine::computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs) { runBatch(jobs, true); }
 
 void LikelihoodEngine::computeLikelihoodsBatch(std::vector<WindowJob> &jobs) { runBatch(jobs, false); }

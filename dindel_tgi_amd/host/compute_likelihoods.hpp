@@ -138,6 +138,9 @@ public:
     // false: the per-base alignments (hpos, 45 % of the result bytes) stay on the device side of the call; lazy views
     // recompute a window on the first get().  Scalars, covered flags and onHap are always delivered.
     void setKeepAlignments(bool v) { keepAlignments_ = v; }
+    // optional: have the calling thread's device cache (arena, staging mirror, streams) of this engine's device made now, for batches of
+    // about `pairs` (haplotype, read) pairs — e.g. while the first batch is still being prepared.  Throws like the batch calls.
+    void warmUp(size_t pairs);
 
     // wall time of the last batch call's three stages (tools/host_adapter_bench.cpp, bench.py)
     double lastPackSeconds = 0.0, lastDeviceSeconds = 0.0, lastUnpackSeconds = 0.0;

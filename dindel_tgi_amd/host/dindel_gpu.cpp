@@ -317,6 +317,7 @@ int main(int argc, char **argv)
                 // diploidGLF reads scalars and covered flags only; the --faster model's indel count (DInDel.cpp:3529) needs hpos
                 engine.setKeepAlignments(faster || realignedBAM);
                 if (packThreads > 0) engine.setHostThreads(packThreads);
+                if (!prepareOnly) engine.warmUp(size_t(batchWindows) * 8 * 200);     // while the first batches are being prepared
                 while (toCompute.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                     Batch &B = *b;

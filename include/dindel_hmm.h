@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 10
+#define DD_ABI_VERSION 11
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -215,6 +215,9 @@ int dd_partition_windows(const dd_batch *b, int n_parts, int32_t *bounds);
 /* The host-pointer entry points keep a device arena, a pinned staging mirror and two streams per host thread between
  * calls (one window per call would otherwise be all allocation overhead); this frees them. */
 void dd_release_cache(void);
+/* Makes the calling thread's cache on `device` at least this big now (device arena, pinned staging mirror) and creates its streams:
+ * a caller that knows work is coming can pay the allocations while its first batch is still being prepared.  Optional. */
+int dd_reserve_cache(int device, size_t device_bytes, size_t pinned_bytes);
 /* Page-locked host memory for the arrays of dd_batch / dd_result: with it the H2D / D2H copies of dd_compute_likelihoods run
  * at full link speed and truly overlap the kernels (pageable memory is staged by the runtime).  Optional: any host pointer
  * works.  dd_host_alloc returns NULL when there is no device or the allocation fails.  Output arrays of dd_compute_likelihoods that
