@@ -230,7 +230,8 @@ int main(int argc, char **argv)
         const BamFile headerBam(opt["bamFile"]); // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
         HaplotypeFixture fixture(opt["hapFile"]);
 
-        const std::string outputPrefix = opt["outputFile"];
+        const std::string outputPrefix = opt["outputFile"], bamPath = opt["bamFile"];
+        const char *dumpReads = getenv("DINDEL_DUMP_READS");                       // diagnostics: what each window hands to the likelihood step
         const std::string glfFile = outputPrefix + ".glf.txt";
         std::ofstream glfOutput(glfFile.c_str());
         if (!glfOutput.is_open()) throw std::string("Cannot open file ").append(glfFile).append(" for writing.");
@@ -257,7 +258,7 @@ int main(int argc, char **argv)
         std::vector<std::thread> prepareWorkers;
         for (int pt = 0; pt < prepareThreads; pt++) prepareWorkers.push_back(std::thread([&, pt]() {
             try {
-                BamFile bam(opt["bamFile"]);
+                BamFile bam(bamPath);
                 std::vector<BamFile *> bams(1, &bam);
                 ReadFetcher fetcher(bams, libraries, rsp);
                 BatchPtr b;
@@ -283,8 +284,8 @@ int main(int argc, char **argv)
                             T.message = skippedMessage(s);
                             T.skipped = true;
                         }
-                        if (const char *dump = getenv("DINDEL_DUMP_READS")) {               // diagnostics: what the window hands to the likelihood step
-                            std::ofstream df((std::string(dump) + "." + std::to_string(T.index)).c_str());
+                        if (dumpReads) {
+                            std::ofstream df((std::string(dumpReads) + "." + std::to_string(T.index)).c_str());
                             df.precision(17);
                             for (size_t r = 0; r < T.reads.size(); r++) {
                                 const Read &R = T.reads[r];
