@@ -20,7 +20,7 @@
 // Options (names follow the reference's CLI, DInDel.cpp:4079-4170):
 //   --bamFile F --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
-//   [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
+//   [--filterReadAux STR] [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
 //   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D | --devices D0,D1,...] [--quiet]
 //   [--outputRealignedBAM]   per window PREFIX.ra.INDEX_TID_LEFT_RIGHT.bam with the reads realigned through the most likely haplotype
 //                     pair (DInDel.cpp:589-620; main model only, like the reference; the haplotype file needs its A records)
@@ -160,7 +160,7 @@ int main(int argc, char **argv)
             "dindel_gpu: the --analysis indels --doDiploid window loop with the likelihood step on the GPU\n"
             "  required: --bamFile F --varFile F --hapFile F --outputFile PREFIX          (writes PREFIX.glf.txt)\n"
             "  model:    [--faster] [--libFile F] [--filterHaplotypes] [--outputRealignedBAM] [--varFileIsOneBased]\n"
-            "            [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]\n"
+            "            [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--filterReadAux STR] [--pError X] [--pMut X] [--maxLengthIndel N]\n"
             "            [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X] [--maxHapReadProd N]\n"
             "  running:  [--batchWindows N] [--device D | --devices D0,D1,...] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N]\n"
             "            [--quiet] [--timing] [--prepareOnly]\n"
@@ -192,6 +192,7 @@ int main(int argc, char **argv)
         rsp.maxReads = size_t(num("maxRead", double(rsp.maxReads))); rsp.maxReadLength = size_t(num("maxReadLength", double(rsp.maxReadLength)));
         rsp.minReadOverlap = int(num("minReadOverlap", rsp.minReadOverlap)); rsp.mapQualThreshold = num("mapQualThreshold", rsp.mapQualThreshold);
         rsp.quiet = has("quiet");
+        if (has("filterReadAux")) rsp.filterReadAux = opt["filterReadAux"];
         DiploidParameters dip;
         dip.priorSNP = num("priorSNP", dip.priorSNP); dip.priorIndel = num("priorIndel", dip.priorIndel);
         dip.filterHaplotypes = has("filterHaplotypes"); dip.quiet = has("quiet");

@@ -197,6 +197,8 @@ public:
     int poolID;
     // the BAM record behind the read (Read::bam), kept only when the realigned BAM is asked for (ReadSelectionParameters::keepRecords)
     std::shared_ptr<const std::vector<uint8_t> > record;
+    // Read::getAuxData() of the record (Read.hpp:223-256), kept only when --filterReadAux asks for it
+    std::string auxData;
     uint32_t getEndPos() const { return endPos; }
     int32_t getBAMMatePos() const { return bamMatePos; }
     // reverse() / complement() — Read.hpp:209-227 (getReads applies both to an unmapped read on its mate's strand)

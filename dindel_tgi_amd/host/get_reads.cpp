@@ -2,7 +2,9 @@
 #include "get_reads.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <iostream>
+#include <sstream>
 
 namespace dindel {
 
@@ -28,6 +30,35 @@ std::pair<double, double> computePositionStatistics(const BamRecord &b)
     }
     var = var / double(totLen);
     return std::pair<double, double>(dmean + double(refPos), var);
+}
+
+std::string auxDataString(const BamRecord &b)
+{
+    std::ostringstream os;
+    const std::vector<uint8_t> &a = b.aux;
+    size_t i = 0;
+    while (i + 3 <= a.size()) {
+        const char k0 = char(a[i]), k1 = char(a[i + 1]), type = char(a[i + 2]);
+        i += 3;
+        os << "\t" << k0 << k1;
+        if (type == 'A') { if (i + 1 > a.size()) break; os << "A:" << char(a[i]); i += 1; }
+        else if (type == 'C' || type == 'c') { if (i + 1 > a.size()) break; os << "i:" << unsigned(a[i]); i += 1; }          // 'c' too: (int) of a uint8_t
+        else if (type == 'S') { if (i + 2 > a.size()) break; os << "i:" << uint16_t(a[i] | (a[i + 1] << 8)); i += 2; }
+        else if (type == 's') { if (i + 2 > a.size()) break; os << "i:" << int16_t(uint16_t(a[i] | (a[i + 1] << 8))); i += 2; }
+        else if (type == 'I' || type == 'i' || type == 'f') {
+            if (i + 4 > a.size()) break;
+            const uint32_t v = uint32_t(a[i]) | (uint32_t(a[i + 1]) << 8) | (uint32_t(a[i + 2]) << 16) | (uint32_t(a[i + 3]) << 24);
+            if (type == 'I') os << "i:" << v;
+            else if (type == 'i') os << "i:" << int32_t(v);
+            else { float f; memcpy(&f, &v, 4); os << "f:" << f; }
+            i += 4;
+        } else if (type == 'Z' || type == 'H') {
+            os << type << ":";
+            while (i < a.size() && a[i]) os << char(a[i++]);
+            i++;
+        } else break;
+    }
+    return os.str();
 }
 
 namespace {
@@ -195,6 +226,7 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                     try {
                         if (wanted) {
                             readBuffer.push_back(makeRead(rec, bam, libraries, pool));
+                            if (params.filterReadAux.size() > 1) readBuffer.back().auxData = auxDataString(rec);
                             if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
                         } else lookupLibrary(rec, bam, libraries, std::string());
                         numReads++;
@@ -203,6 +235,7 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                         numUnknownLib++;
                         if (wanted) {
                             readBuffer.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
+                            if (params.filterReadAux.size() > 1) readBuffer.back().auxData = auxDataString(rec);
                             if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
                         } else lookupLibrary(rec, bam, libraries, "single_end");
                         numReads++;
@@ -300,6 +333,17 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         if (sel[max].flip) { rd.reverseSeq(); rd.complementSeq(); }
         if (rd.matePos == -1 && rd.isPaired() && !rd.mateIsUnmapped()) { nMateposError++; rd.matePos = int32_t(rd.pos); }
         if (rd.isUnmapped()) nUnmapped++;
+    }
+    if (params.filterReadAux.size() > 1) {                                                   // :1233-1243, Read::filterReads (Read.hpp:351-367)
+        const bool exclude = params.filterReadAux[0] != '+';
+        const std::string match = params.filterReadAux.substr(1);
+        size_t keep = 0;
+        for (size_t r = 0; r < out.n; r++) {
+            const bool found = reads[r].auxData.find(match) != std::string::npos;
+            if (found != exclude) { if (keep != r) std::swap(reads[keep], reads[r]); keep++; }
+        }
+        if (!params.quiet) std::cout << "filterAux: " << out.n - keep << " reads were filtered based on match string " << params.filterReadAux << std::endl;
+        out.n = keep;
     }
     if (!params.quiet)
         std::cout << "Number of reads: " << out.n << " out of " << oldNumReads << " # unmapped reads: " << nUnmapped << " numReadsUnknownLib: " << numUnknownLib

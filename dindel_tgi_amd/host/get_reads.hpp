@@ -18,11 +18,17 @@ struct ReadSelectionParameters {         // the DetInDel::Parameters fields getR
     ReadSelectionParameters() : maxReads(10000), maxReadLength(500), minReadOverlap(20), mapQualThreshold(0.99), mapUnmappedReads(false), quiet(true), keepRecords(false) {}
     size_t maxReads; size_t maxReadLength; int minReadOverlap; double mapQualThreshold; bool mapUnmappedReads; bool quiet;
     bool keepRecords;                    // Read::record = the read's BAM record (for --outputRealignedBAM)
+    std::string filterReadAux;           // --filterReadAux: "+text" keeps, "-text" (or any other first character) drops the reads whose
+                                         // auxiliary fields, printed as getAuxData() prints them, contain text (DInDel.cpp:1233-1243)
 };
 
 // Read(const bam1_t *b, libraries, poolID, header, overrideLibName) — reference Read.hpp:120-183.  Throws std::string("Phred error.")
 // or std::string("Cannot find library: NAME").
 Read makeRead(const BamRecord &b, const BamFile &bam, const LibraryCollection &libraries, int poolID, const std::string &overrideLibName = std::string());
+
+// Read::getAuxData — reference Read.hpp:223-256: "\tXX" + "A:c" / "i:number" / "f:number" / "Z:text" per field.  (A field of type B or d
+// is not advanced over in the reference, which then reads on through its bytes; here the text ends in front of such a field.)
+std::string auxDataString(const BamRecord &b);
 
 // Read::computePositionStatistics — reference Read.hpp:261-306
 std::pair<double, double> computePositionStatistics(const BamRecord &b);

@@ -705,8 +705,17 @@ int ddh_parse_inputs_json(const char *varFile, int oneBased, const char *libFile
 
 // DetInDel::getReads over consecutive windows (win: n x {leftPos, rightPos}); prm: {maxReads, maxReadLength, minReadOverlap,
 // mapUnmappedReads}; per window the selected reads in order, or the string thrown
+int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
+                           const char *filterReadAux, char *out, int cap);
 int ddh_get_reads_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
                        char *out, int cap)
+{
+    return ddh_get_reads_aux_json(bamPath, libFile, tid, win, n, prm, mapQualThreshold, "", out, cap);
+}
+
+// the same with --filterReadAux
+int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
+                           const char *filterReadAux, char *out, int cap)
 {
     try {
         BamFile bam(bamPath);
@@ -715,6 +724,7 @@ int ddh_get_reads_json(const char *bamPath, const char *libFile, const char *tid
         if (libFile && *libFile) libs.addFromFile(libFile);
         ReadSelectionParameters p;
         p.maxReads = size_t(prm[0]); p.maxReadLength = size_t(prm[1]); p.minReadOverlap = prm[2]; p.mapUnmappedReads = prm[3] != 0; p.mapQualThreshold = mapQualThreshold;
+        p.filterReadAux = filterReadAux ? filterReadAux : "";
         ReadFetcher f(bams, libs, p);
         std::ostringstream os;
         os.precision(17);

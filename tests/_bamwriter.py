@@ -54,8 +54,12 @@ def encode_record(tid, r):
     for i, ch in enumerate(seq):
         packed[i >> 1] |= NT16.index(ch) << (4 if i % 2 == 0 else 0)
     b += bytes(packed) + bytes(r["qual"])
-    for k, v in r.get("tags", {}).items():
-        b += k.encode() + b"Z" + v.encode() + b"\0"
+    for k, v in r.get("tags", {}).items():                  # "text" = type Z; (type, value) for A c C s S i I f
+        if isinstance(v, str):
+            b += k.encode() + b"Z" + v.encode() + b"\0"
+        else:
+            t, x = v
+            b += k.encode() + t.encode() + (x.encode() if t == "A" else struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[t], x))
     return struct.pack("<I", len(b)) + b, end
 
 

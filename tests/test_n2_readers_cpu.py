@@ -368,3 +368,29 @@ def test_realigned_bam_writer_round_trip(lib, tmp_path):
     # the reader reads what the writer wrote, index-free
     got = call_json(lib.ddh_bam_fetch_json, path.encode(), b"20", -1, 0)
     assert len(got["records"]) == len(recs0)
+
+
+def test_filter_read_aux(lib, tmp_path):
+    """--filterReadAux (DInDel.cpp:1233-1243): the reads whose auxiliary fields — printed as Read::getAuxData prints them (Read.hpp:223-256:
+    "\\tXX" then A:c / i:number / f:number / Z:text; a signed byte comes out unsigned, as there) — contain the text are dropped, or with a
+    leading '+' are the only ones kept; the read-count checks come afterwards."""
+    tagsets = [{"RG": "g1", "NM": ("C", 3), "XT": ("A", "R")}, {"RG": "g2", "NM": ("C", 0), "XT": ("A", "U"), "XS": ("s", -7)},
+               {"NM": ("c", -3), "XF": ("f", 1.5), "XI": ("i", -123456), "XU": ("I", 4000000000), "XH": ("S", 65000)}, {}]
+    recs = []
+    for k in range(24):
+        r = mk("r%02d" % k, 9950 + 3 * k)
+        r["tags"] = tagsets[k % 4]
+        recs.append(r)
+    path = str(tmp_path / "aux.bam")
+    bw.write_bam(path, "@SQ\tSN:20\tLN:100000\n@RG\tID:g1\tLB:l1\n@RG\tID:g2\tLB:l1\n", [("20", 100000)], [(0, r) for r in recs])
+    lib.ddh_get_reads_aux_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_char_p, C.c_char_p, C.c_int]
+    win, prm = (C.c_int * 2)(10000, 10120), (C.c_int * 4)(10000, 500, 20, 0)
+    names = lambda f: sorted(r[0] for r in call_json(lib.ddh_get_reads_aux_json, path.encode(), b"", b"20", win, 1, prm, 0.99, f)[0]["reads"])
+    every = ["r%02d" % k for k in range(24)]
+    aux_text = {0: "\tRGZ:g1\tNMi:3\tXTA:R", 1: "\tRGZ:g2\tNMi:0\tXTA:U\tXSi:-7", 2: "\tNMi:253\tXFf:1.5\tXIi:-123456\tXUi:4000000000\tXHi:65000", 3: ""}
+    assert names(b"") == every and names(b"x") == every                                  # one character: no filter (size() > 1, :1234)
+    for f in ("-XTA:R", "+XTA:R", "-RGZ:g", "+NMi:253", "-i:-7", "+f:1.5\tXIi:-123456", "qXUi:4000000000", "+\tXHi:65000", "-NMi:0\t"):
+        match = f[1:]
+        keep = [n for k, n in enumerate(every) if ((match in aux_text[k % 4]) == (f[0] == "+"))]
+        assert names(f.encode()) == keep, f
+    assert call_json(lib.ddh_get_reads_aux_json, path.encode(), b"", b"20", win, 1, prm, 0.99, b"+no such text")[0] == {"throw": "too_few_reads"}
