@@ -1,5 +1,6 @@
 // bam_reader.cpp — see bam_reader.hpp.
 #include "bam_reader.hpp"
+#include "fast_inflate.hpp"
 #include <algorithm>
 #include <cstring>
 #include <zlib.h>
@@ -66,19 +67,24 @@ bool BgzfReader::loadBlock(int64_t address)
     if (isize > 65536u) throw std::string("corrupt BGZF block");      // a BGZF block holds at most 64 KiB
     CachedBlock &C = cache[cacheNext];
     C.address = -1;                                       // not valid while it is being filled (an exception leaves it so)
-    if (C.data.size() < (isize ? isize : 1)) C.data.resize(isize ? isize : 1);
+    if (C.data.size() < size_t(isize) + 8) C.data.resize(size_t(isize) + 8);      // 8 bytes of slack for fastInflate's block copies
     if (isize) {
-        if (!zs) {
-            z_stream *z = new z_stream;
-            memset(z, 0, sizeof(*z));
-            if (inflateInit2(z, -15) != Z_OK) { delete z; throw std::string("zlib: inflateInit2 failed"); }
-            zs = z;
-        } else if (inflateReset(static_cast<z_stream *>(zs)) != Z_OK) throw std::string("zlib: inflateReset failed");
-        z_stream *z = static_cast<z_stream *>(zs);
-        z->next_in = comp.data(); z->avail_in = uInt(clen);
-        z->next_out = C.data.data(); z->avail_out = uInt(isize);
-        if (inflate(z, Z_FINISH) != Z_STREAM_END) throw std::string("zlib: corrupt BGZF block");
-        if (uint32_t(crc32(crc32(0L, Z_NULL, 0), C.data.data(), isize)) != le32(comp.data() + clen)) throw std::string("BGZF block: CRC mismatch");
+        const uint32_t want_crc = le32(comp.data() + clen);
+        // the own decoder first (fast_inflate.hpp); whatever it declines, or decodes to bytes the CRC does not accept, goes to zlib
+        bool done = fastInflate(comp.data(), size_t(clen), C.data.data(), size_t(isize)) && fastCrc32(0, C.data.data(), isize) == want_crc;
+        if (!done) {
+            if (!zs) {
+                z_stream *z = new z_stream;
+                memset(z, 0, sizeof(*z));
+                if (inflateInit2(z, -15) != Z_OK) { delete z; throw std::string("zlib: inflateInit2 failed"); }
+                zs = z;
+            } else if (inflateReset(static_cast<z_stream *>(zs)) != Z_OK) throw std::string("zlib: inflateReset failed");
+            z_stream *z = static_cast<z_stream *>(zs);
+            z->next_in = comp.data(); z->avail_in = uInt(clen);
+            z->next_out = C.data.data(); z->avail_out = uInt(isize);
+            if (inflate(z, Z_FINISH) != Z_STREAM_END) throw std::string("zlib: corrupt BGZF block");
+            if (fastCrc32(0, C.data.data(), isize) != want_crc) throw std::string("BGZF block: CRC mismatch");
+        }
     }
     C.address = address; C.length = int(isize); C.next = address + bsize + 1;
     cacheNext = (cacheNext + 1) % kCachedBlocks;
@@ -140,7 +146,7 @@ void BgzfWriter::flushBlock()
     deflateEnd(&zs);
     if (rc != Z_STREAM_END || clen + 26 > 65536) throw std::string("zlib: deflate failed on a BGZF block");
     const uint32_t bsize = uint32_t(clen + 25);           // total block size - 1
-    const uint32_t crc = uint32_t(crc32(crc32(0L, Z_NULL, 0), n ? pending.data() : NULL, uInt(n)));
+    const uint32_t crc = fastCrc32(0, pending.data(), n);
     uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, uint8_t(bsize & 255), uint8_t(bsize >> 8)};
     uint8_t tail[8] = {uint8_t(crc), uint8_t(crc >> 8), uint8_t(crc >> 16), uint8_t(crc >> 24), uint8_t(n), uint8_t(n >> 8), uint8_t(n >> 16), uint8_t(n >> 24)};
     if (fwrite(hdr, 1, 18, f) != 18 || fwrite(comp.data(), 1, clen, f) != clen || fwrite(tail, 1, 8, f) != 8) throw std::string("Error writing BGZF block.");

@@ -544,6 +544,7 @@ int ddh_glf_demo(const char *path, const char *thrown, const double *vals)
 // ---- N2: readers and the window's read selection ----
 #include "bam_reader.hpp"
 #include "get_reads.hpp"
+#include "fast_inflate.hpp"
 #include "realigned_bam.hpp"
 #include "window_io.hpp"
 
@@ -599,6 +600,17 @@ int ddh_bam_fetch_seq_json(const char *path, const char *tid, const int *reg, in
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
     }
 }
+
+// fastInflate (fast_inflate.cpp) on a raw DEFLATE stream: 1 = decoded and equal to `want`, 0 = declined (zlib would take over),
+// -1 = decoded something else
+int ddh_fast_inflate_check(const unsigned char *comp, int clen, const unsigned char *want, int n)
+{
+    std::vector<unsigned char> out(size_t(n) + 8, 0xAB);
+    if (!fastInflate(comp, size_t(clen), out.data(), size_t(n))) return 0;
+    return memcmp(out.data(), want, size_t(n)) == 0 ? 1 : -1;
+}
+
+unsigned ddh_fast_crc32(unsigned crc, const unsigned char *buf, int n) { return fastCrc32(crc, buf, size_t(n)); }
 
 // the haplotype fixture as the driver sees it: for the windows asked for, [index, leftPos, rightPos, [[seq, [[kind, key, string, startHap,
 // endHap, startRead, endRead, leftFlankHap, rightFlankHap, leftFlankRead, rightFlankRead], ...]], ...]] (null: no such window)
