@@ -63,18 +63,20 @@ def gen_chunk(job):
             n = int(rng.integers(1, 4))
             if rng.random() < 0.5:
                 seq = hap0[o:o + n]
-                haps.append((hap0[:o] + hap0[o + n:], o, "-" + seq, "V I %d -%s %d %d %d %d %d %d %d %d" % (o, seq, o, o + n - 1, o - 1, o, o, o + n - 1, o - 1, o)))
+                haps.append((hap0[:o] + hap0[o + n:], o, "-" + seq, "V I %d -%s %d %d %d %d %d %d %d %d" % (o, seq, o, o + n - 1, o - 1, o, o, o + n - 1, o - 1, o),
+                             list(range(o)) + list(range(o + n, len(hap0)))))
             else:
                 seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
-                haps.append((hap0[:o] + seq + hap0[o:], o, "+" + seq, "V I %d +%s %d %d %d %d %d %d %d %d" % (o, seq, o, o, o, o + n - 1, o, o, o - 1, o + n)))
+                haps.append((hap0[:o] + seq + hap0[o:], o, "+" + seq, "V I %d +%s %d %d %d %d %d %d %d %d" % (o, seq, o, o, o, o + n - 1, o, o, o - 1, o + n),
+                             list(range(o)) + [-1] * n + list(range(o, len(hap0)))))
             cands.append("%d,%s" % (left + o, haps[-1][2]))
         windows.append("20 %d %d %s" % (left, right, " ".join(cands)))
         fixture.append("W %d %d %d" % (wi, left, right))
         refs_at = lambda skip: ["V %s %d *REF %d %d %d %d %d %d %d %d" % (k, o, o, o, o, o, o, o, o, o) for o in offs if o != skip for k in "IS"]
-        fixture += ["H " + hap0] + refs_at(-1)
-        for h, o, _v, vline in haps:
-            fixture += ["H " + h, vline, "V S %d *REF %d %d %d %d %d %d %d %d" % (o, o, o, o, o, o, o, o, o)] + refs_at(o)
-        alt_h, alt_o, alt_v, _ = haps[int(rng.integers(0, n_var))]
+        fixture += ["H " + hap0, "A " + " ".join(map(str, range(len(hap0))))] + refs_at(-1)      # A: the haplotype's own alignment to the window (hap.ml.hpos)
+        for h, o, _v, vline, amap in haps:
+            fixture += ["H " + h, "A " + " ".join(map(str, amap)), vline, "V S %d *REF %d %d %d %d %d %d %d %d" % (o, o, o, o, o, o, o, o, o)] + refs_at(o)
+        alt_h, alt_o, alt_v, _, _amap = haps[int(rng.integers(0, n_var))]
         truth.append("%d %d %d %s" % (wi, left + alt_o, len(alt_h) - len(hap0), alt_v))      # the heterozygous variant of this window
         alt_full = refs[left - 200:left] + alt_h + refs[right + 1:right + 400]      # the alternative chromosome around the window
         dlen = len(alt_h) - len(hap0)
