@@ -20,6 +20,18 @@ read selection -> kernels -> diploidGLF -> .glf.txt, host/dindel_gpu) on a synth
     python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000] [--total-windows T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+Launched plainly with `--gpus N` (N > 1, no WORLD_SIZE in the environment) the script starts the second form itself: the
+parent touches no GPU, runs `python -m torch.distributed.run --nproc-per-node N` on this file as a fresh child process and exits
+with the child's code (`self_launch`).  Inside a rank, WORLD_SIZE must equal --gpus: anything else is an error, never a silent
+single-GPU run.
+
+At N > 1 the line carries three figures: `value` — every rank runs --windows windows per step and gathers ll + flags to rank 0
+over RCCL (weak; what the driver's scaling table is computed from: the per-GPU work is the N = 1 workload); `configs3` — ONE pass
+over one job of --configs3-windows (default 1,000,000 = BASELINE.json configs[3]) windows split into contiguous blocks per rank
+(strong; a single pass because 25 driver steps of a 41 GPU-second job would not "finish within minutes"); `in_process` — the same
+N devices driven from ONE process through dd_compute_likelihoods_multi (no collective; the form that matches the reference's
+single process, DInDel.cpp:4074), run by rank 0 after the ranks have finished.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -31,6 +43,40 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start N ranks as a fresh child (this process has made no GPU call and
+    makes none), hand its stdout / stderr through (rank 0 prints the one JSON line) and return its exit code."""
+    import argparse as _ap
+    import subprocess
+    pre = _ap.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    known, _ = pre.parse_known_args(argv)
+    if known.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
 
 import numpy as np
 import torch
@@ -133,6 +179,77 @@ def window_loop_leg(faster, windows=40000):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def in_process_leg(pb, params, world, devices, dev, args):
+    """N devices driven from ONE process: dd_compute_likelihoods_multi on a batch of N x --windows windows held in host memory (contiguous
+    window blocks balanced by cells, one host thread + arena + streams per device, no collective) — the form that matches the reference's
+    single process (DInDel.cpp:4074).  Host pointers in, host pointers out: H2D and D2H of every output are inside the time.  The extra
+    leg never takes the headline down: an error is reported in the line instead."""
+    try:
+        import ctypes as C
+        from dindel_tgi_amd.batch import alloc_result
+        lib = capi.load()
+        big = synth.tile(pb, world)
+        arrs, res = alloc_result(big)
+        hb = big.ctypes_batch()
+        devs = (C.c_int32 * len(devices))(*devices)
+        fn = lib.dd_compute_likelihoods_faster_multi if args.faster else lib.dd_compute_likelihoods_multi
+        for _ in range(2):                          # second call: page tables of the result arrays and the per-device arenas are warm
+            t0 = time.perf_counter()
+            rc = fn(C.byref(params), C.byref(hb), C.byref(res), devs, len(devices))
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                return {"error": "dd_compute_likelihoods_multi rc=%d: %s" % (rc, capi.last_error())}
+        n = pb.n_pairs                              # block 0 of the tiled batch is rank 0's own batch: same numbers as its resident launch
+        same = bool(np.array_equal(arrs["ll"][:n], dev.out["ll"][:n].cpu().numpy())) and bool((arrs["status"][:big.n_pairs] == 0).all())
+        lib.dd_release_cache()
+        return {"what": "dd_compute_likelihoods_multi(devices=%s) on %d windows held in (pageable) host memory: one process, one host thread per "
+                        "device, contiguous window blocks, no collective; H2D + kernels + D2H of every output" % (list(devices), big.n_windows),
+                "seconds": dt, "cells_per_s": big.cells / dt, "windows_per_s": big.n_windows / dt, "devices": list(devices),
+                "equals_resident_launch": same}
+    except Exception as e:                          # noqa: BLE001
+        return {"error": repr(e)[:400]}
+
+
+def build_plan(total_windows, rank, world, args, params, device, seed=0x9E3779B9):
+    """Strong scaling: rank r's contiguous block of a `total_windows` job as [(DeviceBatch, repeats)] — sub-batches that fit the int32
+    read-base offsets of a batch; only min(sub-batch, 2500) windows are generated, the rest are replicas (synthetic data either way)."""
+    from dindel_tgi_amd.shard import window_block
+    w0, w1 = window_block(total_windows, rank, world)
+    n_mine = w1 - w0
+    n_sub = max(1, -(-n_mine // args.max_batch_windows))
+    bs = n_mine // n_sub                       # n_sub sub-batches of bs windows (+ one of `rem` windows)
+    rem = n_mine - bs * n_sub
+    gen = min(bs, 2500)
+    base = synth.generate(gen, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len, seed=seed + rank)
+    reps = -(-bs // gen)
+    pb = synth.tile(base, reps).slice_windows(0, bs) if reps * gen != bs else synth.tile(base, reps)
+    plan = [(DeviceBatch(pb, params, device), n_sub)]
+    if rem:
+        plan.append((DeviceBatch(pb.slice_windows(0, rem), params, device), 1))
+    return plan, n_mine
+
+
+def launch_only_rehearsal(args, world, rank):
+    """`--rehearse` in a process that sees no GPU (the CPU test of the launcher): rendezvous over gloo, the same gather of per-pair
+    records with the same shapes on zero-filled host tensors, one JSON line from rank 0 — and no kernel: `value` is null."""
+    pb = synth.generate(min(args.windows, 50), H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len, seed=0x9E3779B9 + rank)
+    n = pb.n_pairs
+    send = {"ll": torch.full((n,), float(rank), dtype=torch.float64), "offHap": torch.zeros(n, dtype=torch.uint8), "offHapHMQ": torch.zeros(n, dtype=torch.uint8)}
+    for k, v in send.items():
+        bufs = [torch.empty_like(v) for _ in range(world)] if rank == 0 else None
+        dist.gather(v, bufs, dst=0)
+        if rank == 0 and k == "ll":
+            assert all(float(b[0]) == float(r) for r, b in enumerate(bufs)), "gather order"
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "read-haplotype HMM cells/s", "value": None, "unit": "cells/s", "n_gpus": world, "ranks": dist.get_world_size(),
+                          "backend": dist.get_backend(), "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "rehearsal": "launch-only: this process sees no GPU, no kernel ran (the likelihood path has no CPU fallback)",
+                          "config": {"workload": "launcher + rendezvous + gather only", "pairs_per_rank": n}}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,10 +265,13 @@ def main():
     ap.add_argument("--no-window-loop", action="store_true", help="skip the BAM -> .glf.txt window-loop leg (N=1)")
     ap.add_argument("--host-api", action="store_true", help="(kept for old command lines: the host-API legs now run by default at N=1)")
     ap.add_argument("--kernel-only", action="store_true",
-                    help="skip the N=1 legs that time the host API (copies included) and the C++ adapter end to end")
+                    help="skip the legs beside the headline figure: at N=1 the host API (copies included) and the C++ adapter end to end, "
+                         "at N>1 the configs[3] pass and the one-process leg")
     ap.add_argument("--total-windows", type=int, default=0,
-                    help="strong scaling: ONE job of this many windows split over the ranks in contiguous blocks "
-                         "(BASELINE.json configs[3] = 1000000); default 0 = weak scaling with --windows per GPU")
+                    help="strong scaling as the HEADLINE figure: ONE job of this many windows split over the ranks in contiguous blocks, "
+                         "every step a full pass (BASELINE.json configs[3] = 1000000); default 0 = weak scaling with --windows per GPU")
+    ap.add_argument("--configs3-windows", type=int, default=1000000,
+                    help="N>1: size of the job whose single strong-scaling pass is reported under `configs3` (0 = skip)")
     ap.add_argument("--max-batch-windows", type=int, default=50000,
                     help="strong scaling: largest sub-batch a rank keeps resident (a batch holds < 2^31 read bases)")
     ap.add_argument("--faster", action="store_true",
@@ -159,22 +279,28 @@ def main():
                          "the JSON line then names that model in `metric` and is not the BASELINE metric")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0 (checks the N>1 code path; "
-                         "the number it prints is not a multi-GPU measurement)")
+                         "the number it prints is not a multi-GPU measurement).  Without any GPU: launcher + rendezvous + gather only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d — run `python bench.py --gpus N` (it starts the ranks itself) or "
+                 "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (world, args.gpus))
     if args.rehearse:
         local_rank = 0
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            if not torch.cuda.is_available():
+                return launch_only_rehearsal(args, world, rank)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+            host_group = dist.new_group(backend="gloo")     # host-side waits that must not park a spinning kernel on a GPU
     assert torch.cuda.is_available(), "bench.py needs a GPU (the likelihood path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -184,21 +310,9 @@ def main():
     # rank r owns windows [r*W, (r+1)*W) of the job; its block is generated from seed+r
     strong = args.total_windows > 0
     if strong:
-        from dindel_tgi_amd.shard import window_block
-        w0, w1 = window_block(args.total_windows, rank, world)
-        n_mine = w1 - w0
-        n_sub = max(1, -(-n_mine // args.max_batch_windows))
-        bs = n_mine // n_sub                       # n_sub sub-batches of bs windows (+ one of `rem` windows)
-        rem = n_mine - bs * n_sub
-        gen = min(bs, 2500)                        # windows really generated; the rest are replicas (synthetic data either way)
-        base = synth.generate(gen, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len, seed=0x9E3779B9 + rank)
-        reps = -(-bs // gen)
-        pb = synth.tile(base, reps).slice_windows(0, bs) if reps * gen != bs else synth.tile(base, reps)
-        plan = [(DeviceBatch(pb, params, device), n_sub)]
-        if rem:
-            plan.append((DeviceBatch(pb.slice_windows(0, rem), params, device), 1))
+        plan, windows_this_rank = build_plan(args.total_windows, rank, world, args, params, device)
         dev = plan[0][0]
-        windows_this_rank = n_mine
+        pb = dev.pb
     else:
         pb = synth.generate(args.windows, H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len,
                             seed=0x9E3779B9 + rank)
@@ -210,56 +324,60 @@ def main():
     step_cells = sum(d.pb.cells * k for d, k in plan)
 
     GATHER = ("ll", "offHap", "offHapHMQ")          # per-pair records the downstream reduction consumes
-    gather_bufs = None
-    if world > 1 and rank == 0:
-        gdev = "cpu" if args.rehearse else device
-        gather_bufs = {k: [torch.empty(dev.out[k].shape, dtype=dev.out[k].dtype, device=gdev) for _ in range(world)]
-                       for k in GATHER}
 
-    def gather(d=None):
-        d = d or dev
-        for k in GATHER:
-            src = d.out[k].cpu() if args.rehearse else d.out[k]
-            if d is dev:
-                dist.gather(src, gather_bufs[k] if rank == 0 else None, dst=0)
-            else:                                   # the remainder sub-batch: same collective on the front of the buffers
-                n = src.numel()
-                dist.gather(src, [b[:n] for b in gather_bufs[k]] if rank == 0 else None, dst=0)
+    def make_gather(main_dev):
+        """The step's one exchange: gather of the per-pair records of `main_dev`-sized (or shorter) batches to rank 0."""
+        bufs = None
+        if world > 1 and rank == 0:
+            gdev = "cpu" if args.rehearse else device
+            bufs = {k: [torch.empty(main_dev.out[k].shape, dtype=main_dev.out[k].dtype, device=gdev) for _ in range(world)] for k in GATHER}
 
-    launch = dev.launch_faster if args.faster else dev.launch
+        def gather(d):
+            for k in GATHER:
+                src = d.out[k].cpu() if args.rehearse else d.out[k]
+                n = src.numel()                     # a remainder sub-batch: same collective on the front of the buffers
+                dist.gather(src, [b[:n] for b in bufs[k]] if rank == 0 else None, dst=0)
+        return gather, bufs
 
-    def step(events=None):
-        for d, k in plan:
-            for _ in range(k):
-                if events is not None and d is dev:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                (d.launch_faster if args.faster else d.launch)()
-                if events is not None and d is dev:
-                    e1.record()
-                    events.append((e0, e1))
-                if world > 1:
-                    gather(d)
+    def timed(the_plan, gather, steps, warmup, events=None):
+        """`warmup` untimed + `steps` timed passes over the_plan, barrier + synchronize either side, MAX over ranks; seconds."""
+        main_dev = the_plan[0][0]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
+        def step(ev):
+            for d, k in the_plan:
+                for _ in range(k):
+                    if ev is not None and d is main_dev:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    (d.launch_faster if args.faster else d.launch)()
+                    if ev is not None and d is main_dev:
+                        e1.record()
+                        ev.append((e0, e1))
+                    if world > 1:
+                        gather(d)
+        for _ in range(warmup):
+            step(None)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(events)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    gather, gather_bufs = make_gather(dev)
     ev = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ev)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(plan, gather, args.steps, args.warmup, ev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")   # one launch of the main (sub-)batch
 
     # sanity: every pair finished with status OK and a finite negative log-likelihood
@@ -270,6 +388,32 @@ def main():
     if world > 1 and rank == 0 and len(plan) == 1:
         # the gathered block of rank 0 is its own result (sanity of the collective's layout)
         assert torch.equal(gather_bufs["ll"][0][:n_pairs].cpu(), dev.out["ll"][:n_pairs].cpu())
+
+    # ---- N > 1: ONE pass over the configs[3] job (strong scaling), every rank its contiguous block ----
+    configs3 = None
+    if world > 1 and not strong and not args.kernel_only and args.configs3_windows > 0:
+        del gather_bufs
+        plan3, mine3 = build_plan(args.configs3_windows, rank, world, args, params, device, seed=0xC0F1C53)
+        gather3, _bufs3 = make_gather(plan3[0][0])
+        plan3[0][0].launch()                                  # the kernels are warm; this touches the new buffers once
+        gather3(plan3[0][0])
+        dt3 = timed(plan3, gather3, 1, 0)
+        cells3 = sum(d.pb.cells * k for d, k in plan3) * (args.configs3_windows / max(mine3, 1))
+        configs3 = {"what": "ONE pass over one job of %d windows x %d haplotypes x %d reads (BASELINE.json configs[3]): rank r computes the r-th "
+                            "contiguous block in sub-batches and gathers ll + flags of every sub-batch to rank 0" % (args.configs3_windows, args.haps, args.reads),
+                    "scaling": "strong", "seconds": dt3, "cells_per_s": cells3 / dt3, "windows_per_s": args.configs3_windows / dt3,
+                    "windows_per_gpu": mine3, "sub_batches_per_gpu": [[d.pb.n_windows, k] for d, k in plan3]}
+        del plan3, gather3, _bufs3
+        torch.cuda.empty_cache()
+
+    # ---- N > 1: the same devices from ONE process (dd_compute_likelihoods_multi), run by rank 0 while the others wait on the host ----
+    in_process = None
+    if world > 1 and not strong and not args.kernel_only:
+        (dist.barrier(group=host_group) if host_group is not None else dist.barrier())
+        if rank == 0:
+            in_process = in_process_leg(pb, params, world, [0] * world if args.rehearse else list(range(world)), dev, args)
+        (dist.barrier(group=host_group) if host_group is not None else dist.barrier())
+
     if rank == 0:
         if strong:      # every rank's block has the same per-window shape: the job's cells = this rank's x (job windows / its windows)
             total_cells = int(step_cells * (args.total_windows / max(windows_this_rank, 1))) * args.steps
@@ -282,7 +426,9 @@ def main():
         achieved = bpp * n_pairs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "read-haplotype HMM cells/s", "value": value, "unit": "cells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": ("%s (RCCL over xGMI)" % dist.get_backend() if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("one job of %d windows over %d GPU(s) (BASELINE.json configs[3] shape), " % (args.total_windows, world) if strong
@@ -307,6 +453,10 @@ def main():
             "valu_fp64": {"achieved_cells_per_s": cells / (kern_ms * 1e-3), "ceiling_cells_per_s": VALU_CELLS_PER_S,
                           "frac": cells / (kern_ms * 1e-3) / VALU_CELLS_PER_S},
         }
+        if configs3 is not None:
+            out["configs3"] = configs3
+        if in_process is not None:
+            out["in_process"] = in_process
         if world == 1 and not strong and not args.kernel_only:
             import ctypes as C
             from dindel_tgi_amd.batch import alloc_result

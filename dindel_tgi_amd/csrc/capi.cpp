@@ -323,7 +323,7 @@ int dd_reserve_cache(int device, size_t device_bytes, size_t pinned_bytes)
 void *dd_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 
@@ -1110,7 +1110,10 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     dd_sizes sz;
     rc = dd_batch_sizes(b, &sz);
     if (rc) return rc;
-    if (sz.n_pairs == 0) return DD_SUCCESS;
+    if (sz.n_pairs == 0) {          // reads without haplotypes: no pair, but onHap[r] is an output per READ (the onHap kernel writes 0 there)
+        if (r->onHap && sz.n_reads > 0) memset(r->onHap, 0, (size_t)sz.n_reads * sizeof(*r->onHap));
+        return DD_SUCCESS;
+    }
     // validate content
     if (!b->hap_seq || !b->read_seq || !b->read_qidx || !b->read_mqidx || !b->read_start || !b->read_flags ||
         !b->win_hap_start || !b->qual_table || !b->mapq_table)
@@ -1507,7 +1510,10 @@ int compute_multi(Model model, const dd_params *p, const dd_batch *b, dd_result 
     if (!r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
     dd_sizes sz;
     if ((rc = dd_batch_sizes(b, &sz))) return rc;
-    if (sz.n_pairs == 0) return DD_SUCCESS;
+    if (sz.n_pairs == 0) {          // reads without haplotypes: no pair, but onHap[r] is an output per READ (the onHap kernel writes 0 there)
+        if (r->onHap && sz.n_reads > 0) memset(r->onHap, 0, (size_t)sz.n_reads * sizeof(*r->onHap));
+        return DD_SUCCESS;
+    }
     const int W = b->n_windows;
     std::vector<int32_t> bounds((size_t)n + 1);
     if ((rc = dd_partition_windows(b, n, bounds.data()))) return rc;

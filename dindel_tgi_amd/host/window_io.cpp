@@ -16,12 +16,68 @@
 namespace dindel {
 
 namespace {
-template <class T> bool from_string(T &t, const std::string &s)      // reference Utils.hpp:40-48
+
+// What `std::istringstream(s) >> std::dec >> t` accepts is the reference's definition of a number (Utils.hpp:40-48: a prefix that parses
+// is enough, "12abc" is 12), so the conversion itself stays with the stream classes; everything around it is this file's own scanner.
+template <class T> bool numberFrom(const std::string &s, T &t)
 {
-    std::istringstream iss(s);
-    return !(iss >> std::dec >> t).fail();
+    std::istringstream in(s);
+    in >> std::dec >> t;
+    return !in.fail();
 }
+
+// Blank-separated words of one text line, with the one property of formatted stream input the reference's callers depend on:
+// `drained` turns true when a word (or the search for one) ran into the end of the line — a line that ends in a blank is NOT drained after
+// its last word, and asking again yields an empty word.
+class Words {
+public:
+    explicit Words(const std::string &line) : p_(line.data()), e_(line.data() + line.size()), drained_(line.empty()) {}
+    bool drained() const { return drained_; }
+    std::string next()
+    {
+        while (p_ < e_ && isspace((unsigned char)*p_)) ++p_;
+        const char *b = p_;
+        while (p_ < e_ && !isspace((unsigned char)*p_)) ++p_;
+        if (p_ == e_) drained_ = true;
+        return std::string(b, p_);
+    }
+private:
+    const char *p_, *e_;
+    bool drained_;
+};
+
+// "pos,variant[,prior[,addCombinatorially]]" — fields end at ',' or ';', except that a separator met while the field is still empty does
+// not end anything and stays in front of the field ("7,,+A" is {"7", ",+A"}).
+void candidateFields(const std::string &word, std::vector<std::string> &fields)
+{
+    fields.clear();
+    std::string cur;
+    for (size_t i = 0; i < word.size(); i++) {
+        const char c = word[i];
+        if ((c == ',' || c == ';') && !cur.empty()) { fields.push_back(cur); cur.clear(); }
+        else cur.push_back(c);
+    }
+    fields.push_back(cur);
 }
+
+bool variantLeadChar(char c) { return c && strchr("-+ACGTR", c) != NULL; }
+
+// One candidate of a window line -> `out` (false: its variant string parsed to nothing and is dropped).  Throws the reference's messages.
+bool candidateFrom(const std::vector<std::string> &f, bool isOneBased, AlignedVariant &out)
+{
+    uint32_t pos = 0;
+    if (!numberFrom(f[0], pos)) throw std::string("Cannot read position");
+    if (isOneBased) pos--;                                       // to zero-based
+    if (!variantLeadChar(f[1].empty() ? '\0' : f[1][0])) throw std::string("Unrecognized variant");
+    double prior = -1.0;
+    if (f.size() > 2 && !numberFrom(f[2], prior)) throw std::string("Cannot read prior/frequency");
+    int combine = 0;
+    if (f.size() > 3 && !numberFrom(f[3], combine)) throw std::string("Cannot add_combinatorial");
+    out = AlignedVariant(f[1], int(pos), prior, combine != 0);
+    return out.getSeq().size() != 0;
+}
+
+} // namespace
 
 VariantFile::VariantFile(const std::string &fileName) : index(0)
 {
@@ -29,73 +85,46 @@ VariantFile::VariantFile(const std::string &fileName) : index(0)
     if (!fin.is_open()) throw std::string("Cannot open variant file ").append(fileName);
 }
 
+// Window file (format of reference VariantFile.hpp:188-289): `tid leftPos rightPos candidate ...`, a word starting with '#' or '%' ends
+// the line.  Outcomes, as there: an AlignedCandidates without variants for an empty line, a line that ends before its third word, a
+// candidate that does not parse (reported on stderr with the line number) or no candidate at all; a std::string thrown for a boundary
+// that is not a number.
 AlignedCandidates VariantFile::getLineVector(bool isOneBased)
 {
-    const AlignedCandidates aligned_empty;
-    uint32_t pos;
-    int leftPos, rightPos;
-    std::string tid, line;
+    std::string line;
     std::getline(fin, line);
-    if (line.empty()) return aligned_empty;
-    std::istringstream is(line);
+    if (line.empty()) return AlignedCandidates();
     index++;
-    if (!is.eof()) is >> tid; else return aligned_empty;
-    if (!is.eof()) {
-        std::string str;
-        is >> str;
-        if (!from_string<int>(leftPos, str)) throw std::string("Cannot read left boundary of region.");
-    } else return aligned_empty;
-    if (!is.eof()) {
-        std::string str;
-        is >> str;
-        if (!from_string<int>(rightPos, str)) throw std::string("Cannot read left boundary of region.");    // (sic) :212
-    } else return aligned_empty;
-    std::vector<AlignedVariant> variants;
-    try {
-        while (!is.eof()) {
-            std::string pvf_str;
-            if (!is.eof()) is >> pvf_str;
-            if (pvf_str.empty()) break;
-            if (pvf_str[0] == '#' || pvf_str[0] == '%') break;
-            std::vector<std::string> els;                          // split at ';' or ',' (:233-241)
-            int lastpos = 0;
-            for (int x = 0; x < int(pvf_str.size()); x++) {
-                if ((pvf_str[size_t(x)] == ';' || pvf_str[size_t(x)] == ',') && x - lastpos > 0) {
-                    els.push_back(pvf_str.substr(size_t(lastpos), size_t(x - lastpos)));
-                    lastpos = x + 1;
-                }
-            }
-            els.push_back(pvf_str.substr(size_t(lastpos), pvf_str.size() - size_t(lastpos)));
-            if (els.size() < 2) {
-                std::cerr << "Error reading line in variantfile!\n";
-            } else {
-                double freq = -1.0;
-                bool addComb = false;
-                if (!from_string<uint32_t>(pos, els[0])) throw std::string("Cannot read position");
-                if (isOneBased) pos--;
-                const std::string &col = els[1];
-                if (col.size() == 0 || (col[0] != '-' && col[0] != '+' && col[0] != 'A' && col[0] != 'C' && col[0] != 'G' && col[0] != 'T' && col[0] != 'R'))
-                    throw std::string("Unrecognized variant");
-                if (els.size() > 2 && !from_string<double>(freq, els[2])) throw std::string("Cannot read prior/frequency");
-                if (els.size() > 3) {
-                    int addc;
-                    if (!from_string<int>(addc, els[3])) throw std::string("Cannot add_combinatorial");
-                    if (addc) addComb = true;
-                }
-                AlignedVariant variant(col, int(pos), freq, addComb);
-                if (variant.getSeq().size() != 0) variants.push_back(variant);
-            }
-        }
-    } catch (std::string &err) {
-        std::cerr << "Could not parse variants in line " << index << " in variants file." << std::endl;
-        std::cerr << "Error: " << err << std::endl;
-        return aligned_empty;
+    Words words(line);
+    const std::string tid = words.next();
+    if (words.drained()) return AlignedCandidates();
+    int bounds[2];
+    for (int k = 0; k < 2; k++) {
+        if (!numberFrom(words.next(), bounds[k])) throw std::string("Cannot read left boundary of region.");   // the same text for both
+        if (k == 0 && words.drained()) return AlignedCandidates();
     }
-    if (variants.size() == 0) {
+    std::vector<AlignedVariant> found;
+    std::vector<std::string> fields;
+    std::string problem;
+    while (!words.drained() && problem.empty()) {
+        const std::string word = words.next();
+        if (word.empty() || word[0] == '#' || word[0] == '%') break;
+        candidateFields(word, fields);
+        if (fields.size() < 2) { std::cerr << "Error reading line in variantfile!\n"; continue; }
+        try {
+            AlignedVariant v;
+            if (candidateFrom(fields, isOneBased, v)) found.push_back(v);
+        } catch (const std::string &message) { problem = message; }
+    }
+    if (!problem.empty()) {
+        std::cerr << "Could not parse variants in line " << index << " in variants file." << std::endl << "Error: " << problem << std::endl;
+        return AlignedCandidates();
+    }
+    if (found.empty()) {
         std::cerr << "Could not parse any variants in line: " << index << " SKIPPING." << std::endl;
-        return aligned_empty;
+        return AlignedCandidates();
     }
-    return AlignedCandidates(tid, variants, leftPos, rightPos);
+    return AlignedCandidates(tid, found, bounds[0], bounds[1]);
 }
 
 LibraryCollection::LibraryCollection()
@@ -103,49 +132,45 @@ LibraryCollection::LibraryCollection()
     (*this)["single_end"] = Library(std::vector<double>(2000, 1.0));         // Library(0), Library.hpp:44-50
 }
 
+// Library file (format of reference Library.hpp:143-241): sections `#LIB <name>` followed by `<insertSize> <count>` rows, insert sizes
+// counting up from 0 without gaps; the first empty line ends the file.  A section is kept when the next header (or the end) is reached;
+// a header that follows no rows only renames the section, and rows in front of the first header run on into the first named section —
+// both as the reference's reader behaves.  Throws "Library error" (a name used twice), "Library error." (gap in the insert sizes,
+// negative count), "Cannot read library name ".
 void LibraryCollection::addFromFile(const std::string &fileName)
 {
-    std::ifstream fin(fileName.c_str());
-    if (!fin.is_open()) throw std::string("Cannot open variant file ").append(fileName);       // (sic) Library.hpp:147
-    int numLibs = 0, numLines = 0, prev = -1;
+    std::ifstream file(fileName.c_str(), std::ios::in | std::ios::binary);
+    if (!file.is_open()) throw std::string("Cannot open variant file ").append(fileName);       // (sic) the reference's text
+    std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+
+    std::string name;
     std::vector<double> counts;
-    std::string libName;
-    while (!fin.eof()) {
-        std::string line;
-        std::getline(fin, line);
-        numLines++;
+    auto keep = [&]() {
+        if (count(name)) { std::cerr << "Duplicate library IDs: " << name << std::endl; throw std::string("Library error"); }
+        (*this)[name] = Library(counts);
+    };
+    for (size_t at = 0; at < text.size();) {
+        size_t nl = text.find('\n', at);
+        if (nl == std::string::npos) nl = text.size();
+        const std::string line = text.substr(at, nl - at);
+        at = nl + 1;
         if (line.empty()) break;
-        std::istringstream is(line);
-        std::string isize_str, count_str;
-        int isize = -1;
-        double count = -1;
-        is >> isize_str;
-        if (isize_str == "#LIB") {
-            if (counts.size() > 0 && !libName.empty()) {
-                if (find(libName) != end()) throw std::string("Library error");                   // duplicate library IDs
-                (*this)[libName] = Library(counts);
-                numLibs++;
-                counts.clear();
-                prev = -1;
-            }
-            std::string label;
-            is >> label;
-            libName = label;
-            if (label.empty()) throw std::string("Cannot read library name ");
+        Words words(line);
+        const std::string first = words.next();
+        if (first == "#LIB") {
+            if (!counts.empty() && !name.empty()) { keep(); counts.clear(); }
+            name = words.next();
+            if (name.empty()) throw std::string("Cannot read library name ");
             continue;
         }
-        if (!from_string<int>(isize, isize_str)) std::cerr << "Error reading from library file" << std::endl;
-        is >> count_str;
-        if (!from_string<double>(count, count_str)) std::cerr << "Error reading from library file" << std::endl;
-        if (isize != prev + 1) throw std::string("Library error.");                              // insert sizes must be consecutive
-        if (count < 0) throw std::string("Library error.");
-        counts.push_back(count);
-        prev = isize;
+        int insertSize = -1;
+        double n = -1;
+        if (!numberFrom(first, insertSize) | !numberFrom(words.next(), n)) std::cerr << "Error reading from library file" << std::endl;
+        if (insertSize != int(counts.size())) { std::cerr << "Library insert sizes must be consecutive" << std::endl; throw std::string("Library error."); }
+        if (n < 0) { std::cerr << "Library insert size count is negative.." << std::endl; throw std::string("Library error."); }
+        counts.push_back(n);
     }
-    if (find(libName) != end()) throw std::string("Library error");
-    (*this)[libName] = Library(counts);
-    numLibs++;
-    if (numLibs == 0) std::cerr << "Could not find any libraries. Are the headers specified correctly?" << std::endl;
+    keep();                                                                   // the last section, whatever it holds
 }
 
 double LibraryCollection::getMaxInsertSize() const

@@ -114,6 +114,46 @@ def test_window_file_and_library_file(lib, tmp_path):
     assert L["libB"][0] == 300 and got["maxInsertSize"] == 2000
 
 
+def test_window_and_library_file_corner_cases(lib, tmp_path):
+    """The behaviours of the two text formats that come from the reference reading them with formatted stream input
+    (VariantFile.hpp:188-289, Library.hpp:143-241) — the parsers here are written from the format, so each one is pinned."""
+    def windows(text, one_based=0):
+        f = tmp_path / "w.txt"
+        f.write_text(text)
+        return call_json(lib.ddh_parse_inputs_json, str(f).encode(), one_based, b"")
+    assert windows("20 10 20\n20 30")["windows"] == []                        # no candidates / line ends after two words: skipped
+    assert windows("20 \n") == {"throw": "Cannot read left boundary of region."}        # a blank after the last word is not the end of the line
+    assert windows("20 x 20 15,+A\n") == {"throw": "Cannot read left boundary of region."}
+    assert windows("20 10 y 15,+A\n") == {"throw": "Cannot read left boundary of region."}    # the same text for the right boundary
+    assert windows("20 10abc 20 15,+A\n")["windows"][0]["leftPos"] == 10       # a numeric prefix is a number
+    got = windows("20 10 20 15 16,+A\n")["windows"]                            # a candidate without separator: reported, the rest kept
+    assert [v[:2] for v in got[0]["variants"]] == [[16, "+A"]]
+    assert windows("20 10 20 15,,+A\n")["windows"] == []                       # {"15", ",+A"}: unrecognised variant, the line is dropped
+    assert windows("20 10 20 15,+A,zz\n")["windows"] == [] and windows("20 10 20 15,+A,0.1,q\n")["windows"] == []
+    assert windows("20 10 20 q,+A\n")["windows"] == []
+    assert windows("20 10 20 0,+A\n", 1)["windows"][0]["variants"][0][0] == -1  # one-based 0 wraps like the reference's uint32
+    got = windows("20 10 20 15;+AC;0.25 %16,+T 17,-G\n")["windows"]
+    assert got[0]["variants"] == [[15, "+AC", 15, 0.25, 0]]
+
+    def libs(text):
+        f = tmp_path / "l.txt"
+        f.write_text(text)
+        return call_json(lib.ddh_parse_inputs_json, b"", 0, str(f).encode())
+    rows = lambda n, first=0: "".join("%d 2\n" % i for i in range(first, first + n))
+    L = libs("#LIB a\n" + rows(30) + "\n#LIB b\n" + rows(40))["libraries"]       # the first empty line ends the file
+    assert set(L) == {"single_end", "a"} and L["a"][0] == 30
+    L = libs(rows(3) + "#LIB a\n" + rows(27, 3))["libraries"]                    # rows in front of the first header run on into it
+    assert set(L) == {"single_end", "a"} and L["a"][0] == 30
+    L = libs("#LIB a\n#LIB b\n" + rows(12))["libraries"]                         # a header after no rows only renames
+    assert set(L) == {"single_end", "b"} and L["b"][0] == 12
+    assert libs("#LIB a\n" + rows(5) + "#LIB a\n" + rows(5)) == {"throw": "Library error"}
+    assert libs("#LIB single_end\n" + rows(5)) == {"throw": "Library error"}
+    assert libs("#LIB a\n0 1\n2 1\n") == {"throw": "Library error."}
+    assert libs("#LIB a\n0 1\n1 -1\n") == {"throw": "Library error."}
+    assert libs("#LIB\n0 1\n") == {"throw": "Cannot read library name "}
+    assert call_json(lib.ddh_parse_inputs_json, b"", 0, str(tmp_path / "absent").encode())["throw"].startswith("Cannot open variant file ")
+
+
 def mk(qname, pos, flag=0, mapq=60, L=100, cigar=None, mtid=-1, mpos=-1, seq=None):
     return dict(qname=qname, flag=flag, pos=pos, mapq=mapq, cigar=("%dM" % L if cigar is None else cigar), seq=seq or "ACGT" * (L // 4) + "A" * (L % 4),
                 qual=[30] * L, mtid=mtid, mpos=mpos, isize=0, tags={})

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
                 REP8(X)
 #undef X
             } else if (OP == 9) {      // the hysteresis step of the right->middle pass: add, compare, 3 selects
-#define X(i) asm volatile("v_add_f64 %1, %0, %3\n v_cmp_gt_f64 vcc, %2, %1\n v_cndmask_b32 %4, %4, %5, vcc" : "+v"(a[i]), "+v"(b[i]) : "v"(a[(i + 1) & 7]), "v"(seed), "v"(u[i]), "v"(u[(i + 1) & 7]) : "vcc");
+#define X(i) asm volatile("v_add_f64 %1, %0, %4\n v_cmp_gt_f64 vcc, %3, %1\n v_cndmask_b32 %2, %2, %5, vcc" : "+v"(a[i]), "+v"(b[i]), "+v"(u[i]) : "v"(a[(i + 1) & 7]), "v"(seed), "v"(u[(i + 1) & 7]) : "vcc");
                 REP8(X)
 #undef X
             } else if (OP == 10) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
                 REP8(X)
 #undef X
             } else if (OP == 13) {
-#define X(i) asm volatile("v_cmp_ge_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a[i]) : "v"(b[i]), "v"(u[i]), "v"(u[(i + 1) & 7]) : "vcc");
+#define X(i) asm volatile("v_cmp_ge_f64 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(a[i]), "+v"(u[i]) : "v"(b[i]), "v"(u[(i + 1) & 7]) : "vcc");
                 REP8(X)
 #undef X
             }
@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     double s = 0;
     for (int i = 0; i < 8; i++) s += a[i] + b[i] + u[i] + f[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < 1024u * 256u) out[slot] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -98,7 +99,8 @@ static unsigned long long *g_cyc = nullptr;
 
 template <int OP> static void run(const char *name, int instr_per_x)
 {
-    for (int w = 1; w <= 3; w++) {   // the product kernels run 2-3 waves per SIMD (1024-thread workgroups of this loop faulted intermittently on the test box)
+    for (int w = 1; w <= 4; w++) {   // (round 2's w = 4 fault: OP 9 / OP 13 wrote u[i] through an input-only operand, so the register that also held
+                                     //  threadIdx.x drifted and the final store left the buffer; every written register is an output operand now)
         const int threads = 256 * w, blocks = 256;
         if (!g_out) {                                  // once, for the largest launch
             CHECK(hipMalloc(&g_out, sizeof(double) * 1024 * 256));
