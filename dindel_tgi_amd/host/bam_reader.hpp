@@ -33,6 +33,31 @@ struct BamRecord {                       // bam1_t / bam1_core_t with the variab
     const char *auxString(const char tag[2]) const;      // value of a Z-type field, NULL if absent (bam_aux_get)
 };
 
+// A BAM record's bytes as the file holds them (without the 4-byte length word): the fixed fields read in place, the variable
+// part located, nothing copied.  `d` must hold a record that decodeCore accepted (lengths consistent with `n`).
+struct RawBamView {
+    const uint8_t *d; size_t n;
+    RawBamView(const uint8_t *bytes, size_t len) : d(bytes), n(len) {}
+    static uint32_t u32(const uint8_t *p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+    int32_t tid() const { return int32_t(u32(d)); }
+    int32_t pos() const { return int32_t(u32(d + 4)); }
+    uint32_t nameBytes() const { return d[8]; }                          // with the terminating NUL
+    uint8_t mapq() const { return d[9]; }
+    uint32_t nCigar() const { return uint32_t(d[12]) | (uint32_t(d[13]) << 8); }
+    uint16_t flag() const { return uint16_t(d[14] | (d[15] << 8)); }
+    int32_t lSeq() const { return int32_t(u32(d + 16)); }
+    int32_t mtid() const { return int32_t(u32(d + 20)); }
+    int32_t mpos() const { return int32_t(u32(d + 24)); }
+    const char *name() const { return reinterpret_cast<const char *>(d + 32); }
+    size_t nameLength() const { return nameBytes() ? nameBytes() - 1 : 0; }
+    uint32_t cigar(uint32_t k) const { return u32(d + 32 + nameBytes() + 4 * size_t(k)); }
+    const uint8_t *packedBases() const { return d + 32 + nameBytes() + 4 * size_t(nCigar()); }
+    char base(int32_t x) const { return "=ACMGRSVTWYHKDBN"[(packedBases()[x >> 1] >> ((~x & 1) << 2)) & 15]; }      // bam_nt16_rev_table
+    const uint8_t *qualities() const { return packedBases() + (size_t(lSeq()) + 1) / 2; }
+    const uint8_t *aux() const { return qualities() + size_t(lSeq()); }
+    size_t auxBytes() const { return size_t((d + n) - aux()); }
+};
+
 class BgzfReader {
 public:
     BgzfReader();
@@ -101,10 +126,14 @@ private:
     bool nextRaw(std::vector<uint8_t> &d);
     static void decodeCore(const std::vector<uint8_t> &d, BamRecord &b);     // fixed fields + CIGAR
     static void decodeRest(const std::vector<uint8_t> &d, BamRecord &b);
-    // Where the previous fetch on this reference met its first record ending behind its `beg`.  In a coordinate-sorted file
-    // every record in front of it ends at or before that `beg`, so a later fetch with the same or a larger `beg` cannot be
-    // handed any of them: it starts its scan there instead of at the head of the bin's chunk.
-    struct Resume { int tid, beg; uint64_t voffset; bool valid; Resume() : tid(-1), beg(0), voffset(0), valid(false) {} } resume;
+    // Two marks left by the previous fetch on a reference, each saying "every record in front of `voffset` ends at or before `beg`" — in
+    // a coordinate-sorted file such records cannot overlap a later region that starts at `beg` or behind it, so the next fetch starts its
+    // scan at the mark instead of at the head of the bin's chunk.  [0]: the first record that ended behind the fetch's own `beg`;
+    // [1]: the first one that ended behind the fetch's `end` (or, if none did, the place behind the last record that started in front of
+    // `end`) — the one that serves a caller walking along the chromosome, whose next region starts where this one ended.  (Records the
+    // scan did not visit because their bins do not overlap the region lie in front of a mark only if they start in front of `end`, and
+    // then they end at or before `beg`.)
+    struct Resume { int tid, beg; uint64_t voffset; bool valid; Resume() : tid(-1), beg(0), voffset(0), valid(false) {} } resume[2];
     std::vector<uint8_t> raw;
     struct Chunk { uint64_t beg, end; bool operator<(const Chunk &o) const { return beg < o.beg; } };
     struct RefIndex { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; };
@@ -122,9 +151,16 @@ private:
 template <class F> void BamFile::fetchImpl(int tid, int beg, int end, F callback, bool whole)
 {
     const std::vector<Chunk> chunks = chunksFor(tid, beg, end);
-    const bool resumable = resume.valid && resume.tid == tid && beg >= resume.beg;
-    const uint64_t from = resumable ? resume.voffset : 0;
-    bool noted = false;
+    // the later of the two marks that hold for this `beg` (see Resume)
+    uint64_t from = 0;
+    for (int k = 0; k < 2; k++) if (resume[k].valid && resume[k].tid == tid && beg >= resume[k].beg && resume[k].voffset > from) from = resume[k].voffset;
+    bool noted = false, notedEnd = false;
+    uint64_t afterLast = from;                    // just behind the last record scanned (all of them start in front of `end`)
+    struct SetEndMark {                           // however the scan ends: everything in front of `at` ends at or before `end`
+        Resume &r; int tid, end; const bool &found; const uint64_t &at;
+        ~SetEndMark() { if (!found && at) { r.tid = tid; r.beg = end; r.voffset = at; r.valid = true; } }
+    } setEndMark = { resume[1], tid, end, notedEnd, afterLast };
+    resume[1].valid = false;
     BamRecord b;
     for (size_t i = 0; i < chunks.size(); i++) {
         if (chunks[i].end <= from) continue;
@@ -134,8 +170,11 @@ template <class F> void BamFile::fetchImpl(int tid, int beg, int end, F callback
             if (!nextRaw(raw)) return;
             decodeCore(raw, b);
             if (b.tid != tid || b.pos >= end) return;                    // past the region: the file is sorted
-            if (int(b.endPos()) > beg) {
-                if (!noted) { resume.tid = tid; resume.beg = beg; resume.voffset = here; resume.valid = true; noted = true; }
+            const int recordEnd = int(b.endPos());
+            if (!notedEnd && recordEnd > end) { resume[1].tid = tid; resume[1].beg = end; resume[1].voffset = here; resume[1].valid = true; notedEnd = true; }
+            afterLast = bgzf.tell();
+            if (recordEnd > beg) {
+                if (!noted) { resume[0].tid = tid; resume[0].beg = beg; resume[0].voffset = here; resume[0].valid = true; noted = true; }
                 if (b.pos < end) {                                       // is_overlap
                     if (whole) decodeRest(raw, b);
                     if (!callback(b)) return;

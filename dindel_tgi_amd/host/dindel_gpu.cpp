@@ -11,6 +11,14 @@
 // The stages run as a pipeline: the main thread reads the window file and cuts it into batches; --prepareThreads workers, each
 // with its own handle on the BAM file and its own read buffer, prepare whole batches side by side; one thread feeds the GPU in
 // batch order; one thread (with --reduceThreads helpers, each window into its own buffer) reduces and writes in window order.
+// --bamFiles LIST (one path per line, first word of the line; reference DInDel.cpp:64-88): the files are pools of one read buffer
+// (Read::fetchFuncVectorPooled, poolID = position in the list).  With several pools the buffer's ORDER depends on its history — a
+// window's new records are appended pool after pool behind the survivors of the windows before — and std::sort's order inside a tie of
+// mapping qualities follows it, so a worker does not start a batch with an empty buffer: it first replays read selection over the
+// batch's look-back (the preceding windows of the chromosome back to one whose reads have all left the buffer by the batch's first
+// window), which leaves the buffer in the state the window-by-window loop would have.  What a worker cannot see is a window of an
+// earlier batch skipped AFTER read selection (an exception of the likelihood or genotyping step): the reference empties the buffer
+// after it, here the buffer carries on — same reads, possibly another order inside ties for the next ~(2 maxInsert + 200) bases.
 // One BAM file: with a single pool the read buffer's reset (after a skipped window in the reference, DInDel.cpp:1401-1408; at
 // the head of every batch here) does not change which reads a window sees — the buffer always holds the file's reads starting in
 // [leftPos - maxInsert - 200, rightPos + maxInsert), in file order — so preparing windows ahead of their predecessors'
@@ -18,7 +26,7 @@
 // region" fires on buffer size + records fetched > 100 * maxRead, which at a batch's first window is counted as after a reset.)
 //
 // Options (names follow the reference's CLI, DInDel.cpp:4079-4170):
-//   --bamFile F --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
+//   --bamFile F | --bamFiles LIST   --varFile F [--varFileIsOneBased] --hapFile F --outputFile PREFIX [--libFile F] [--faster] [--filterHaplotypes]
 //   [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--pError X] [--pMut X] [--maxLengthIndel N]
 //   [--filterReadAux STR] [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X]
 //   [--maxHapReadProd N] [--batchWindows N] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N] [--device D | --devices D0,D1,...] [--quiet]
@@ -66,6 +74,9 @@ struct Batch {
     std::vector<WindowJob> jobs;
     std::vector<size_t> jobOf;
     std::vector<int> toRelease;          // windows of the batch's previous use whose parsed haplotypes are no longer needed
+    // several BAM pools: the windows in front of the batch (same chromosome, file order) whose read selection is replayed first
+    struct Before { std::string tid; uint32_t leftPos, rightPos; };
+    std::vector<Before> lookBack;
 };
 typedef std::unique_ptr<Batch> BatchPtr;
 
@@ -172,14 +183,15 @@ int main(int argc, char **argv)
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
         a = a.substr(2);
         if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" || a == "outputRealignedBAM" ||
-            a == "prepareOnly") opt[a] = "1";
+            a == "prepareOnly" || a == "noLookBack") opt[a] = "1";
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::cerr << "Option --" << a << " needs a value\n"; return 2; }
     }
     auto has = [&](const char *k) { return opt.find(k) != opt.end(); };
     auto num = [&](const char *k, double dflt) { return has(k) ? atof(opt[k].c_str()) : dflt; };
-    for (const char *need : {"bamFile", "varFile", "hapFile", "outputFile"})
+    for (const char *need : {"varFile", "hapFile", "outputFile"})
         if (!has(need)) { std::cerr << "Please specify --" << need << "\n"; return 1; }
+    if (!has("bamFile") && !has("bamFiles")) { std::cerr << "Error: Specify either --bamFile or --bamFiles." << std::endl; return 1; }   // DInDel.cpp:4215-4218
     try {
         const std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
         ObservationModelParameters obs;
@@ -228,10 +240,25 @@ int main(int argc, char **argv)
             rsp.mapUnmappedReads = true;
             obs.mapUnmappedReads = true;
         }
-        const BamFile headerBam(opt["bamFile"]); // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
+        std::vector<std::string> bamPaths;       // --bamFile wins when both are given (DInDel.cpp:4220-4226)
+        if (has("bamFile")) bamPaths.push_back(opt["bamFile"]);
+        else {
+            std::ifstream list(opt["bamFiles"].c_str());
+            if (!list.is_open()) { std::cout << "Cannot open file with BAM files:  " << opt["bamFiles"] << std::endl; throw std::string("File open error."); }
+            std::string line;
+            while (std::getline(list, line)) {
+                std::istringstream is(line);
+                std::string fname;
+                is >> fname;
+                if (!fname.empty()) bamPaths.push_back(fname);
+            }
+            if (bamPaths.empty()) throw std::string("No BAM file in ").append(opt["bamFiles"]);
+        }
+        const BamFile headerBam(bamPaths[0]);    // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
+        for (size_t i = 1; i < bamPaths.size(); i++) { const BamFile probe(bamPaths[i]); (void)probe; }
         HaplotypeFixture fixture(opt["hapFile"]);
 
-        const std::string outputPrefix = opt["outputFile"], bamPath = opt["bamFile"];
+        const std::string outputPrefix = opt["outputFile"];
         const char *dumpReads = getenv("DINDEL_DUMP_READS");                       // diagnostics: what each window hands to the likelihood step
         const std::string glfFile = outputPrefix + ".glf.txt";
         std::ofstream glfOutput(glfFile.c_str());
@@ -246,6 +273,7 @@ int main(int argc, char **argv)
         std::condition_variable done_cv;
         bool reduceDone = false;
         std::string fatal;
+        std::atomic<int> fatalExit(1);
         BatchPool recycled;
         Channel toPrepare(size_t(prepareThreads) + 1);
         OrderedChannel toCompute(computeThreads + 1), toReduce(computeThreads + 1);
@@ -259,18 +287,32 @@ int main(int argc, char **argv)
         std::vector<std::thread> prepareWorkers;
         for (int pt = 0; pt < prepareThreads; pt++) prepareWorkers.push_back(std::thread([&, pt]() {
             try {
-                BamFile bam(bamPath);
-                std::vector<BamFile *> bams(1, &bam);
+                std::vector<std::unique_ptr<BamFile> > handles;
+                std::vector<BamFile *> bams;
+                for (size_t i = 0; i < bamPaths.size(); i++) { handles.push_back(std::unique_ptr<BamFile>(new BamFile(bamPaths[i]))); bams.push_back(handles.back().get()); }
                 ReadFetcher fetcher(bams, libraries, rsp);
+                std::vector<Read> replayed;
                 BatchPtr b;
                 while (toPrepare.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                     for (size_t i = 0; i < b->toRelease.size(); i++) fixture.release(b->toRelease[i]);
                     b->toRelease.clear();
                     std::string oldTid;
+                    bool primed = false;
+                    if (!b->lookBack.empty()) {               // several pools: bring the buffer to the state the windows in front left it in
+                        fetcher.newChromosome();
+                        for (size_t k = 0; k < b->lookBack.size(); k++) {
+                            const Batch::Before &W = b->lookBack[k];
+                            bool skipped = false;
+                            try { fetcher.getReads(W.tid, W.leftPos, W.rightPos, replayed); } catch (std::string &) { skipped = true; }
+                            fetcher.windowDone(skipped, W.leftPos);
+                        }
+                        oldTid = b->lookBack.back().tid;
+                        primed = true;
+                    }
                     for (size_t i = 0; i < b->tasks.size(); i++) {
                         WindowTask &T = b->tasks[i];
-                        if (i == 0 || T.tid != oldTid) { fetcher.newChromosome(); oldTid = T.tid; }     // DInDel.cpp:1327-1333
+                        if ((i == 0 && !primed) || T.tid != oldTid) { fetcher.newChromosome(); oldTid = T.tid; }     // DInDel.cpp:1327-1333
                         try {
                             fetcher.getReads(T.tid, T.fileLeftPos, T.fileRightPos, T.reads);
                             const WindowHaplotypes *wh = fixture.find(T.index);
@@ -290,7 +332,7 @@ int main(int argc, char **argv)
                             df.precision(17);
                             for (size_t r = 0; r < T.reads.size(); r++) {
                                 const Read &R = T.reads[r];
-                                df << R.qname << " " << int32_t(R.pos) << " " << R.mapQual << " " << R.matePos << " " << R.mateLen << " " << R.isUnmapped() << " " << R.isPaired()
+                                df << R.qname << " " << R.poolID << " " << int32_t(R.pos) << " " << R.mapQual << " " << R.matePos << " " << R.mateLen << " " << R.isUnmapped() << " " << R.isPaired()
                                    << " " << R.mateIsUnmapped() << " " << R.mateIsReverse() << " " << R.mateSameTid << " " << R.posStat.first << " "
                                    << (R.library ? R.library->getMaxInsertSize() : -1) << " " << R.seq.seq << "\n";
                             }
@@ -301,6 +343,7 @@ int main(int argc, char **argv)
                     if (!toCompute.push(b)) break;
                 }
             } catch (std::string &s) { fail(s); }
+            catch (ReadFetcher::FatalError &e) { fatalExit = e.exitCode; fail(e.message); }   // the reference's exit() paths of getReads end the run here too
             catch (HaplotypeFixture::Error &e) { fail(e.message); }     // a malformed haplotype file ends the run, whichever window met it
             catch (std::exception &e) { fail(e.what()); }
         }));
@@ -429,9 +472,26 @@ int main(int argc, char **argv)
             uint32_t oldLeftPos = 0;
             BatchPtr batch = recycled.take();
             size_t nTasks = 0;                                                                // batch->tasks[nTasks...] are left-overs of an earlier use
+            const bool pooled = bamPaths.size() > 1 && !has("noLookBack");        // --noLookBack: diagnostics (every batch starts with an empty buffer)
+            const uint32_t bufferSpan = 2u * uint32_t(libraries.getMaxInsertSize()) + 200u;    // a record fetched for a window has left the buffer this far on
+            std::deque<Batch::Before> recent;                                                 // the chromosome's windows so far that a later batch may need
             auto flush = [&]() {
                 batch->seq = seq++;
                 batch->tasks.resize(nTasks);
+                batch->lookBack.clear();
+                if (pooled && nTasks) {
+                    // windows of recent[] in front of the batch's first one; the replay starts at the last of them whose own fetch
+                    // (everything up to rightPos + maxInsert) has left the buffer when the batch's first window is selected
+                    const WindowTask &first = batch->tasks[0];
+                    auto gone = [&](const Batch::Before &W) {          // W's own fetch has left the buffer by the batch's first window (or never was in it)
+                        return W.tid != first.tid || uint64_t(W.rightPos) + bufferSpan <= uint64_t(first.fileLeftPos);
+                    };
+                    const size_t n = recent.size() - nTasks;                                   // recent[] ends with this batch's windows
+                    size_t from = n;
+                    while (from > 0 && recent[from - 1].tid == first.tid) { from--; if (gone(recent[from])) break; }
+                    batch->lookBack.assign(recent.begin() + long(from), recent.begin() + long(n));
+                    while (recent.size() > nTasks + 1 && gone(recent[1])) recent.pop_front();   // recent[0] stays a start later batches can use
+                }
                 const bool ok = toPrepare.push(batch);
                 batch = recycled.take();
                 nTasks = 0;
@@ -455,6 +515,10 @@ int main(int argc, char **argv)
                 T.fileLeftPos = T.leftPos = uint32_t(cand.leftPos); T.fileRightPos = T.rightPos = uint32_t(cand.rightPos);
                 T.haps = NULL; T.skipped = false; T.message = "ok";
                 T.index = ++index;
+                if (pooled) {
+                    Batch::Before W = { T.tid, T.fileLeftPos, T.fileRightPos };
+                    recent.push_back(W);
+                }
                 if (int(nTasks) >= batchWindows && !flush()) break;
             }
             if (nTasks) flush();
@@ -470,7 +534,7 @@ int main(int argc, char **argv)
         for (size_t t = 0; t < computeWorkers.size(); t++) computeWorkers[t].join();
         for (int t = 0; t < computeThreads; t++) { t_compute += t_compute_of[size_t(t)]; t_pack += t_pack_of[size_t(t)]; t_device += t_device_of[size_t(t)]; t_unpack += t_unpack_of[size_t(t)]; }
         glfOutput.close();
-        if (!fatal.empty()) throw fatal;
+        if (!fatal.empty()) { std::cerr << "Exception: " << fatal << std::endl; return fatalExit.load(); }
         if (rc) return rc;
         if (!has("quiet")) std::cout << "windows: " << nWindows << " skipped: " << nSkipped << " -> " << glfFile << std::endl;
         if (has("timing")) {

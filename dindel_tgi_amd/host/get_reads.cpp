@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <sstream>
 
@@ -102,85 +103,120 @@ Read makeRead(const BamRecord &b, const BamFile &bam, const LibraryCollection &l
 }
 
 namespace {
-// The selection below works on one small record per buffered read instead of on copies of the reads: the reference copies the
-// whole buffer (reads = readBuffer, :1055-1057), edits the copies, sorts them and keeps the head.  The buffer spans
-// 2 * maxInsert + 200 bases around the window and only a fraction of it overlaps the window, so here the edits go into
-// Selection records, those are sorted, and only the reads that are kept are copied.  std::sort is driven by the comparator's
-// answers alone, so sorting the records with the reference's comparator (mapQual descending, :890-895) leaves them in the
-// order it leaves the reads in.
-struct Selection { double mapQual; uint32_t idx; int32_t matePos, mateLen; bool flip; };
-bool byMapQualDescending(const Selection &r1, const Selection &r2) { return r1.mapQual > r2.mapQual; }
+const std::vector<double> &phredTable()          // Phred values are bytes: Read::phredToProb of each, once (none of the 256 throws)
+{
+    static const std::vector<double> table = []() {
+        std::vector<double> t(256);
+        for (int q = 0; q < 256; q++) t[size_t(q)] = Read::phredToProb(double(q));
+        return t;
+    }();
+    return table;
+}
 
-uint64_t hashName(const std::string &s)
+// Read::computePositionStatistics on the record's bytes (the CIGAR in place)
+std::pair<double, double> positionStatistics(const RawBamView &v)
+{
+    const uint32_t n = v.nCigar();
+    if (n == 0) return std::pair<double, double>(-1.0, -1.0);
+    int32_t pos = 0, mean = 0, totLen = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t c = v.cigar(k);
+        const int op = int(c & 15u);
+        const int32_t len = int32_t(c >> 4);
+        if (op == BAM_CMATCH) { mean += len * (pos - totLen); totLen += len; }
+        if (op == BAM_CMATCH || op == BAM_CDEL || op == BAM_CSOFT_CLIP || op == BAM_CHARD_CLIP) pos += len;
+    }
+    const double dmean = double(mean) / double(totLen);
+    double var = 0.0;
+    pos = 0; totLen = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t c = v.cigar(k);
+        const int op = int(c & 15u);
+        const int32_t len = int32_t(c >> 4);
+        if (op == BAM_CMATCH) { var += double(len) * (double(pos - totLen) - dmean) * (double(pos - totLen) - dmean); totLen += len; }
+        if (op == BAM_CMATCH || op == BAM_CDEL || op == BAM_CSOFT_CLIP || op == BAM_CHARD_CLIP) pos += len;
+    }
+    var = var / double(totLen);
+    return std::pair<double, double>(dmean + double(uint32_t(v.pos())), var);
+}
+
+uint64_t hashBytes(const char *s, size_t n)
 {
     uint64_t h = 1469598103934665603ull;                                                     // FNV-1a
-    for (size_t i = 0; i < s.size(); i++) { h ^= uint8_t(s[i]); h *= 1099511628211ull; }
+    for (size_t i = 0; i < n; i++) { h ^= uint8_t(s[i]); h *= 1099511628211ull; }
     return h;
 }
 
-// qname -> the buffer indices carrying it, ascending (what the reference keeps in two hash_map<string, list<int>>, :1063-1072)
-class NameIndex {
-public:
-    NameIndex(const std::deque<Read> &reads) : reads_(reads)
-    {
-        size_t cap = 16;
-        while (cap < 2 * reads.size()) cap <<= 1;
-        mask_ = cap - 1;
-        slot_.assign(cap, -1);
-        next_.assign(reads.size(), -1);
-        tail_.assign(reads.size(), -1);
-        count_.assign(reads.size(), 0);
-        hash_.resize(reads.size());
-        for (size_t r = 0; r < reads.size(); r++) {
-            const uint64_t h = hash_[r] = hashName(reads[r].qname);
-            size_t at = size_t(h) & mask_;
-            for (;;) {
-                const int head = slot_[at];
-                if (head < 0) { slot_[at] = int(r); tail_[r] = int(r); count_[r] = 1; break; }
-                if (hash_[size_t(head)] == h && reads[size_t(head)].qname == reads[r].qname) {
-                    next_[size_t(tail_[size_t(head)])] = int(r); tail_[size_t(head)] = int(r); count_[size_t(head)]++;
-                    break;
-                }
-                at = (at + 1) & mask_;
-            }
-        }
+// The reference copies the whole buffer (reads = readBuffer, :1055-1057), edits the copies, sorts them and keeps the head.  The
+// buffer spans 2 * maxInsert + 200 bases around the window and only a fraction of it overlaps the window, so here the edits go
+// into one small Selection per buffered alignment, those are sorted, and a Read is built only for the ones that are kept.
+// std::sort is driven by the comparator's answers alone, so sorting the Selections with the reference's comparator (mapQual
+// descending, :890-895) leaves them in the order it leaves the reads in.
+struct ByMapQualDescending { template <class S> bool operator()(const S &r1, const S &r2) const { return r1.mapQual > r2.mapQual; } };
+}
+
+// The Read the reference's BAM constructor makes of this record (Read.hpp:120-183), into `dst` — every field is assigned, so
+// `dst` may be a Read of an earlier window (its strings and vectors keep their storage).
+void ReadFetcher::buildRead(const BufferedAlignment &a, Read &r) const
+{
+    const RawBamView v = bytesOf(a);
+    const std::vector<double> &table = phredTable();
+    r.mapQual = a.mapQual;
+    r.pos = uint32_t(a.pos);
+    const size_t L = size_t(a.length);
+    r.seq.seq.resize(L);
+    r.qual.resize(L);
+    if (L) {
+        static const char nt16[] = "=ACMGRSVTWYHKDBN";                // bam_nt16_rev_table
+        const uint8_t *packed = v.packedBases(), *q = v.qualities();
+        char *bases = &r.seq.seq[0];
+        double *probs = r.qual.data();
+        const double *t = table.data();
+        size_t x = 0;
+        for (; x + 1 < L; x += 2) { const uint8_t two = packed[x >> 1]; bases[x] = nt16[two >> 4]; bases[x + 1] = nt16[two & 15]; }
+        if (x < L) bases[x] = nt16[packed[x >> 1] >> 4];
+        for (x = 0; x < L; x++) probs[x] = t[q[x]];
     }
-    bool anyNameMoreThan(int n) const { for (size_t r = 0; r < count_.size(); r++) if (count_[r] > n) return true; return false; }
-    // first buffer index with this name (-1: none); walk the others with next()
-    int first(const std::string &qname) const
-    {
-        const uint64_t h = hashName(qname);
-        size_t at = size_t(h) & mask_;
-        for (;;) {
-            const int head = slot_[at];
-            if (head < 0) return -1;
-            if (hash_[size_t(head)] == h && reads_[size_t(head)].qname == qname) return head;
-            at = (at + 1) & mask_;
-        }
+    r.seq.indels.clear(); r.seq.snps.clear(); r.seq.refHpos.clear();
+    r.posStat = positionStatistics(v);
+    r.unmapped = a.isUnmapped(); r.paired = a.isPaired(); r.mateUnmapped = a.mateIsUnmapped();
+    r.reverse = a.isReverse(); r.mateReverse = (a.flag & BAM_FMREVERSE) != 0; r.mateSameTid = a.mateSameTid;
+    r.onReverseStrand = r.reverse;
+    r.poolID = a.pool;
+    r.matePos = a.mpos;
+    r.mateLen = -1;
+    r.qname.assign(v.name(), v.nameLength());
+    r.bamPos = a.pos; r.bamMatePos = a.mpos; r.endPos = a.endPos;
+    r.library = a.library;
+    if (params.keepRecords) r.record = std::make_shared<const std::vector<uint8_t> >(v.d, v.d + v.n); else r.record.reset();
+    if (params.filterReadAux.size() > 1) {
+        BamRecord tmp;
+        tmp.aux.assign(v.aux(), v.aux() + v.auxBytes());
+        r.auxData = auxDataString(tmp);
+    } else r.auxData.clear();
+}
+
+void ReadFetcher::compactArena()
+{
+    std::vector<uint8_t> fresh;
+    fresh.reserve(arena.size() - deadBytes + (1u << 16));
+    for (size_t r = 0; r < readBuffer.size(); r++) {
+        BufferedAlignment &a = readBuffer[r];
+        const size_t at = fresh.size();
+        fresh.insert(fresh.end(), arena.begin() + long(a.bytesAt), arena.begin() + long(a.bytesAt + a.nBytes));
+        a.bytesAt = at;
     }
-    int next(int r) const { return next_[size_t(r)]; }
-    // calls f(idx) for every read called qname whose isUnmapped() == unmapped, ascending; returns how many there are
-    template <class F> int each(const std::string &qname, bool unmapped, F f) const
-    {
-        int n = 0;
-        for (int i = first(qname); i >= 0; i = next(i)) if (reads_[size_t(i)].isUnmapped() == unmapped) { n++; f(i); }
-        return n;
-    }
-private:
-    const std::deque<Read> &reads_;
-    size_t mask_;
-    std::vector<int> slot_, next_, tail_, count_;
-    std::vector<uint64_t> hash_;
-};
+    arena.swap(fresh);
+    deadBytes = 0;
 }
 
 void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t rightPos, std::vector<Read> &reads)
 {
     const bool reset = resetReadBuffer;
-    if (leftPos < oldLeftPos) throw std::string("Windows are not sorted!");                  // the reference exits (:899-902)
+    if (leftPos < oldLeftPos) { const FatalError e = { "Windows are not sorted!", 3 }; throw e; }      // the reference exits (:899-902)
     // `reads` comes back holding the selection and nothing else, as after the reference's reads.clear() (:904); what it held
     // on entry is overwritten in place, so a caller that hands the same vector in again (dindel_gpu recycles its batches) spares
-    // the allocator one string and one vector per read
+    // the allocator two strings and one vector per read
     struct Trim {
         std::vector<Read> &v; size_t n;
         ~Trim() { v.resize(n); }
@@ -196,23 +232,24 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
 
     if (reset) {                                                                             // :936-941
         readBuffer.clear();
+        arena.clear();
+        deadBytes = 0;
         oldRightFetchReadPos = rightFetchReadPos;
     } else {
-        size_t drop = 0;                                                                     // :942-961
-        while (drop < readBuffer.size() && uint32_t(readBuffer[drop].bamPos) < leftMostReadPos) drop++;
-        bool prefixOnly = true;                                                              // one sorted file: the reads to drop are the oldest ones
-        for (size_t r = drop; r < readBuffer.size() && prefixOnly; r++) if (uint32_t(readBuffer[r].bamPos) < leftMostReadPos) prefixOnly = false;
-        if (prefixOnly) readBuffer.erase(readBuffer.begin(), readBuffer.begin() + long(drop));
-        else {
-            size_t keep = 0;
-            for (size_t r = 0; r < readBuffer.size(); r++)
-                if (!(uint32_t(readBuffer[r].bamPos) < leftMostReadPos)) { if (keep != r) std::swap(readBuffer[keep], readBuffer[r]); keep++; }
-            readBuffer.resize(keep);
+        size_t keep = 0;                                                                     // :942-961, order kept
+        for (size_t r = 0; r < readBuffer.size(); r++) {
+            if (uint32_t(readBuffer[r].pos) < leftMostReadPos) deadBytes += readBuffer[r].nBytes;
+            else { if (keep != r) readBuffer[keep] = readBuffer[r]; keep++; }
         }
+        readBuffer.resize(keep);
+        if (deadBytes > (1u << 20) && 2 * deadBytes > arena.size()) compactArena();
         if (leftMostReadPos < oldRightFetchReadPos) leftFetchReadPos = oldRightFetchReadPos;
     }
     int numReads = int(readBuffer.size());
     if (leftFetchReadPos <= rightFetchReadPos) {                                             // :981-993
+        const std::vector<double> &table = phredTable();
+        const LibraryCollection::const_iterator se = libraries.find("single_end");
+        const Library *singleEnd = se == libraries.end() ? NULL : &se->second;
         for (size_t b = 0; b < myBams.size(); b++) {
             BamFile &bam = *myBams[b];
             const int maxNumReads = int(params.maxReads * 100);
@@ -220,25 +257,32 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
             bam.fetchCore(bam.getTID(tid), int(leftFetchReadPos), int(rightFetchReadPos), [&](BamRecord &rec) -> bool {
                 if (!((rec.flag & BAM_FDUP) || (rec.flag & BAM_FQCFAIL) || (rec.flag & 0x800))) {              // Read.hpp:392
                     // :998-1004: a read starting left of the fetched stretch was picked up by an earlier window; the reference
-                    // builds it and drops it afterwards.  Here it is counted and its library looked up (what can throw), not built.
+                    // builds it and drops it afterwards.  Either way only what can throw is done now: the library lookup (a paired
+                    // read's RG tag); a record that is wanted is buffered as its bytes.
                     const bool wanted = uint32_t(rec.pos) >= leftFetchReadPos;
-                    if (wanted || (rec.flag & BAM_FPAIRED)) bam.complete(rec);      // name, bases, qualities; the RG tag of a paired read
+                    if (rec.flag & BAM_FPAIRED) bam.complete(rec);
+                    const Library *library = NULL;
                     try {
-                        if (wanted) {
-                            readBuffer.push_back(makeRead(rec, bam, libraries, pool));
-                            if (params.filterReadAux.size() > 1) readBuffer.back().auxData = auxDataString(rec);
-                            if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
-                        } else lookupLibrary(rec, bam, libraries, std::string());
-                        numReads++;
+                        // an unpaired record's library is "single_end" whatever its tags say (Read::getLibraryName, Read.hpp:189-201)
+                        library = (!(rec.flag & BAM_FPAIRED) && singleEnd) ? singleEnd : lookupLibrary(rec, bam, libraries, std::string());
                     } catch (std::string &s) {
                         if (s.find("Cannot find library") == std::string::npos) throw;
                         numUnknownLib++;
-                        if (wanted) {
-                            readBuffer.push_back(makeRead(rec, bam, libraries, pool, "single_end"));
-                            if (params.filterReadAux.size() > 1) readBuffer.back().auxData = auxDataString(rec);
-                            if (params.keepRecords) readBuffer.back().record = std::make_shared<const std::vector<uint8_t> >(bam.rawRecord());
-                        } else lookupLibrary(rec, bam, libraries, "single_end");
-                        numReads++;
+                        library = lookupLibrary(rec, bam, libraries, "single_end");
+                    }
+                    numReads++;
+                    if (wanted) {
+                        const std::vector<uint8_t> &raw = bam.rawRecord();
+                        const RawBamView v(raw.data(), raw.size());
+                        BufferedAlignment a;
+                        a.mapQual = table[rec.qual];                                         // Read.hpp:124-129
+                        a.pos = rec.pos; a.mpos = rec.mpos; a.endPos = rec.endPos(); a.length = uint32_t(rec.l_qseq);
+                        a.flag = rec.flag; a.mateSameTid = rec.tid == rec.mtid; a.pool = pool;
+                        a.library = library;
+                        a.nameHash = hashBytes(v.name(), v.nameLength());
+                        a.bytesAt = arena.size(); a.nBytes = uint32_t(raw.size());
+                        arena.insert(arena.end(), raw.begin(), raw.end());
+                        readBuffer.push_back(a);
                     }
                 }
                 if (numReads > maxNumReads) throw std::string("Too many reads in region");
@@ -248,28 +292,64 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         oldRightFetchReadPos = rightFetchReadPos;
     }
     const size_t oldNumReads = readBuffer.size();
-    const NameIndex names(readBuffer);
-    if (names.anyNameMoreThan(2)) throw std::string("duplicate reads!");                     // :1027-1044
-    // the reference's two indices (:1063-1072) are one here: a name's reads are walked in buffer order and told apart by
-    // isUnmapped()
-    const NameIndex &mates = names;
-    std::vector<Selection> sel(readBuffer.size());
-    for (size_t r = 0; r < sel.size(); r++) {
-        sel[r].mapQual = readBuffer[r].mapQual; sel[r].idx = uint32_t(r); sel[r].matePos = readBuffer[r].matePos; sel[r].mateLen = readBuffer[r].mateLen;
+    const size_t N = readBuffer.size();
+
+    // qname -> the buffer indices carrying it, ascending (what the reference keeps in two hash_map<string, list<int>>, :1063-1072, and
+    // in the qnameCount of its duplicate check, :1027-1044): one open-addressing table over the name hashes, rebuilt per window — the
+    // hashes are stored with the alignments, so this is a pass over N small records.
+    size_t cap = 16;
+    while (cap < 2 * N) cap <<= 1;
+    const size_t mask = cap - 1;
+    nameSlot.assign(cap, -1);
+    nameNext.assign(N, -1); nameTail.resize(N); nameCount.assign(N, 0);
+    auto sameName = [&](size_t x, size_t y) {
+        const RawBamView vx = bytesOf(readBuffer[x]), vy = bytesOf(readBuffer[y]);
+        return vx.nameLength() == vy.nameLength() && memcmp(vx.name(), vy.name(), vx.nameLength()) == 0;
+    };
+    bool tooMany = false;
+    for (size_t r = 0; r < N; r++) {
+        const uint64_t h = readBuffer[r].nameHash;
+        for (size_t at = size_t(h) & mask;; at = (at + 1) & mask) {
+            const int32_t head = nameSlot[at];
+            if (head < 0) { nameSlot[at] = int32_t(r); nameTail[r] = int32_t(r); nameCount[r] = 1; break; }
+            if (readBuffer[size_t(head)].nameHash == h && sameName(size_t(head), r)) {
+                nameNext[size_t(nameTail[size_t(head)])] = int32_t(r); nameTail[size_t(head)] = int32_t(r);
+                if (++nameCount[size_t(head)] > 2) tooMany = true;
+                break;
+            }
+        }
+    }
+    if (tooMany) throw std::string("duplicate reads!");                                      // :1027-1044
+    // calls f(idx) for every buffered alignment named like `r` whose isUnmapped() == unmapped, ascending; returns how many there are
+    auto eachNamedLike = [&](size_t r, bool unmapped, const std::function<void(int)> &f) -> int {
+        const uint64_t h = readBuffer[r].nameHash;
+        int32_t head = -1;
+        for (size_t at = size_t(h) & mask;; at = (at + 1) & mask) {
+            head = nameSlot[at];
+            if (head < 0 || (readBuffer[size_t(head)].nameHash == h && sameName(size_t(head), r))) break;
+        }
+        int n = 0;
+        for (int32_t i = head; i >= 0; i = nameNext[size_t(i)]) if (readBuffer[size_t(i)].isUnmapped() == unmapped) { n++; f(int(i)); }
+        return n;
+    };
+
+    sel.resize(N);
+    for (size_t r = 0; r < N; r++) {
+        sel[r].mapQual = readBuffer[r].mapQual; sel[r].idx = uint32_t(r); sel[r].matePos = readBuffer[r].mpos; sel[r].mateLen = -1;
         sel[r].flip = false;
     }
     int numTIDmismatch = 0, numOrphan = 0, numOrphanUnmapped = 0, numInRegion = 0;
     double minMapQual = params.mapQualThreshold;
     if (minMapQual < 0.0) minMapQual = 0.0;
-    for (int r = 0; r < int(readBuffer.size()); r++) {                                       // :1095-1213
-        const Read &rd = readBuffer[size_t(r)];
+    for (int r = 0; r < int(N); r++) {                                                       // :1095-1213
+        const BufferedAlignment &rd = readBuffer[size_t(r)];
         Selection &out = sel[size_t(r)];
         bool filter = false;
-        if (rd.size() > params.maxReadLength) filter = true;
-        if (rd.getEndPos() < leftMostReadPos || uint32_t(rd.pos) > rightMostReadPos) filter = true;
-        const int rpos = int(int32_t(rd.pos));
+        if (size_t(rd.length) > params.maxReadLength) filter = true;
+        if (rd.endPos < leftMostReadPos || uint32_t(rd.pos) > rightMostReadPos) filter = true;
+        const int rpos = int(rd.pos);
         if (!rd.isUnmapped()) {
-            if (rpos + int(rd.size()) < int(leftPos) + params.minReadOverlap || rpos > int(rightPos) - params.minReadOverlap) {
+            if (rpos + int(rd.length) < int(leftPos) + params.minReadOverlap || rpos > int(rightPos) - params.minReadOverlap) {
                 filter = true;
             } else if (rd.mateIsUnmapped() == false) {
                 if (!rd.mateSameTid) {
@@ -277,23 +357,23 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                 } else {
                     filter = true;                                                           // :1125-1127 (mateIsUnmapped() == false here)
                     bool inconsistent = false;
-                    const int n = mates.each(rd.qname, false, [&](int idx) {
+                    const int n = eachNamedLike(size_t(r), false, [&](int idx) {
                         if (idx != r) {
-                            out.mateLen = int32_t(readBuffer[size_t(idx)].size());
-                            out.matePos = int32_t(readBuffer[size_t(idx)].pos);
+                            out.mateLen = int32_t(readBuffer[size_t(idx)].length);
+                            out.matePos = readBuffer[size_t(idx)].pos;
                             filter = false;
-                            if (out.matePos != rd.getBAMMatePos()) inconsistent = true;
+                            if (out.matePos != rd.mpos) inconsistent = true;
                         }
                     });
                     if (n > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
-                    if (inconsistent) throw std::string("matepos inconsistency!");           // the reference exits
+                    if (inconsistent) { const FatalError e = { "matepos inconsistency!", 1 }; throw e; }       // the reference exits (:1134-1137)
                     if (filter == true) numOrphan++;                                         // (also when the name is not indexed, :1118-1121)
                 }
             } else {                                                                         // mate unmapped (:1148-1166)
-                out.matePos = int32_t(rd.pos);
+                out.matePos = rd.pos;
                 filter = true;
-                const int n = mates.each(rd.qname, true, [&](int idx) {
-                    if (idx != r) { out.mateLen = int32_t(readBuffer[size_t(idx)].size()); filter = false; }
+                const int n = eachNamedLike(size_t(r), true, [&](int idx) {
+                    if (idx != r) { out.mateLen = int32_t(readBuffer[size_t(idx)].length); filter = false; }
                 });
                 if (n > 2) std::cerr << "HUH? DUPLICATE READ LABELS???" << std::endl;
                 if (filter == true) numOrphan++;
@@ -301,13 +381,13 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
             if (filter == false) numInRegion++;
         } else if (params.mapUnmappedReads) {                                                // :1171-1209
             int idx = -1;
-            const int n = mates.each(rd.qname, false, [&](int i) { if (idx < 0) idx = i; });
+            const int n = eachNamedLike(size_t(r), false, [&](int i) { if (idx < 0) idx = i; });
             if (n == 0) { numOrphanUnmapped++; filter = true; }
             else {
-                if (n != 1) throw std::string("UNMAPPED READ HAS MORE THAN ONE MATE!");      // the reference exits
-                const Read &mate = readBuffer[size_t(idx)];
-                const int maxInsert = mate.getLibrary().getMaxInsertSize(), minInsert = 0;
-                const uint32_t mpos = mate.pos;
+                if (n != 1) { const FatalError e = { "UNMAPPED READ HAS MORE THAN ONE MATE!", 1 }; throw e; }  // the reference exits (:1180-1183)
+                const BufferedAlignment &mate = readBuffer[size_t(idx)];
+                const int maxInsert = mate.library->getMaxInsertSize(), minInsert = 0;
+                const uint32_t mpos = uint32_t(mate.pos);
                 uint32_t range_l, range_r;
                 if (mate.isReverse()) { range_l = mpos - uint32_t(maxInsert); range_r = mpos - uint32_t(minInsert); }
                 else { range_l = mpos + uint32_t(minInsert); range_r = mpos + uint32_t(maxInsert); }
@@ -315,8 +395,8 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
                     numInRegion++;
                     filter = false;
                     out.mapQual = sel[size_t(idx)].mapQual;                                  // the mate's value as edited so far (-1 if it was filtered)
-                    out.matePos = int32_t(mate.pos);
-                    out.mateLen = int32_t(mate.size());
+                    out.matePos = mate.pos;
+                    out.mateLen = int32_t(mate.length);
                     if (rd.isReverse() == mate.isReverse()) out.flip = true;                 // reverse() + complement()
                 } else filter = true;
             }
@@ -324,11 +404,12 @@ void ReadFetcher::getReads(const std::string &tid, uint32_t leftPos, uint32_t ri
         if (filter == true) out.mapQual = -1.0;                                              // :1210
     }
     int nUnmapped = 0, nMateposError = 0;
-    std::sort(sel.begin(), sel.end(), byMapQualDescending);                                  // :1218
+    std::sort(sel.begin(), sel.end(), ByMapQualDescending());                               // :1218
     for (size_t max = 0; max < params.maxReads && max < sel.size(); max++) {                 // :1219-1227
         if (sel[max].mapQual < minMapQual) break;
-        if (out.n < reads.size()) reads[out.n] = readBuffer[sel[max].idx]; else reads.push_back(readBuffer[sel[max].idx]);
+        if (out.n == reads.size()) reads.push_back(Read());
         Read &rd = reads[out.n++];
+        buildRead(readBuffer[sel[max].idx], rd);
         rd.mapQual = sel[max].mapQual; rd.matePos = sel[max].matePos; rd.mateLen = sel[max].mateLen;
         if (sel[max].flip) { rd.reverseSeq(); rd.complementSeq(); }
         if (rd.matePos == -1 && rd.isPaired() && !rd.mateIsUnmapped()) { nMateposError++; rd.matePos = int32_t(rd.pos); }

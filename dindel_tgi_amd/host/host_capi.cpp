@@ -1,5 +1,6 @@
 // host_capi.cpp — small extern "C" hooks so the pytest suite can drive the C++ host adapter
 // (LikelihoodEngine) through ctypes.  Not part of the drop-in boundary.
+#include <memory>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -726,12 +727,27 @@ int ddh_get_reads_json(const char *bamPath, const char *libFile, const char *tid
 }
 
 // the same with --filterReadAux
+int ddh_get_reads_pools_json(const char *bamPaths, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
+                             const char *filterReadAux, int withBuffer, char *out, int cap);
 int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
                            const char *filterReadAux, char *out, int cap)
 {
+    return ddh_get_reads_pools_json(bamPath, libFile, tid, win, n, prm, mapQualThreshold, filterReadAux, 0, out, cap);
+}
+
+// several BAM files as pools of one buffer (bamPaths: one path per line); withBuffer: every window also reports the buffer's order,
+// [qname, pool] per buffered alignment
+int ddh_get_reads_pools_json(const char *bamPaths, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,
+                             const char *filterReadAux, int withBuffer, char *out, int cap)
+{
     try {
-        BamFile bam(bamPath);
-        std::vector<BamFile *> bams(1, &bam);
+        std::vector<std::unique_ptr<BamFile> > handles;
+        std::vector<BamFile *> bams;
+        {
+            std::istringstream list(bamPaths);
+            std::string path;
+            while (std::getline(list, path)) if (!path.empty()) { handles.push_back(std::unique_ptr<BamFile>(new BamFile(path))); bams.push_back(handles.back().get()); }
+        }
         LibraryCollection libs;
         if (libFile && *libFile) libs.addFromFile(libFile);
         ReadSelectionParameters p;
@@ -741,6 +757,7 @@ int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char 
         std::ostringstream os;
         os.precision(17);
         os << "[";
+        std::vector<std::pair<std::string, int> > buffered;
         for (int w = 0; w < n; w++) {
             std::vector<Read> reads;
             os << (w ? "," : "");
@@ -750,18 +767,27 @@ int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char 
                 os << "{\"reads\":[";
                 for (size_t r = 0; r < reads.size(); r++)
                     os << (r ? "," : "") << "[\"" << reads[r].qname << "\"," << int32_t(reads[r].pos) << "," << reads[r].mapQual << "," << reads[r].matePos << "," << reads[r].mateLen << ","
-                       << int(reads[r].isUnmapped()) << ",\"" << reads[r].seq.seq << "\"," << reads[r].posStat.first << "]";
-                os << "]}";
+                       << int(reads[r].isUnmapped()) << ",\"" << reads[r].seq.seq << "\"," << reads[r].posStat.first << (withBuffer ? "," : "") << (withBuffer ? std::to_string(reads[r].poolID) : std::string()) << "]";
+                os << "]";
             } catch (std::string &e) {
-                os << "{\"throw\":\"" << e << "\"}";
+                os << "{\"throw\":\"" << e << "\"";
                 skipped = true;
             }
+            if (withBuffer) {
+                f.buffered(buffered);
+                os << ",\"buffer\":[";
+                for (size_t r = 0; r < buffered.size(); r++) os << (r ? "," : "") << "[\"" << buffered[r].first << "\"," << buffered[r].second << "]";
+                os << "]";
+            }
+            os << "}";
             f.windowDone(skipped, uint32_t(win[2 * w]));
         }
         os << "]";
         return emit(os.str(), out, cap);
     } catch (std::string &e) {
         return emit(std::string("{\"throw\":\"") + e + "\"}", out, cap);
+    } catch (ReadFetcher::FatalError &e) {                 // where the reference calls exit(): the whole run ends, not one window
+        return emit(std::string("{\"fatal\":\"") + e.message + "\",\"exitCode\":" + std::to_string(e.exitCode) + "}", out, cap);
     }
 }
 

@@ -207,40 +207,47 @@ void parseFixtureStretch(const char *p, const char *end, int lineNo, const std::
             where << what << " in line " << lineNo << " of " << fileName;
             return where.str();
         };
-        auto integer = [&](size_t k, const char *what) -> long {      // field k as a whole decimal number
+        auto integer = [&](size_t k, const char *what) -> long {      // field k as a whole decimal number ([+-]digits, nothing else)
             if (k >= tok.size()) throw bad(what);
-            const std::string t(tok[k].first, tok[k].second);
-            char *stop = NULL;
-            const long v = strtol(t.c_str(), &stop, 10);
-            if (stop == t.c_str() || *stop) throw bad(what);
-            return v;
+            const char *c = tok[k].first, *e = c + tok[k].second;
+            const bool neg = *c == '-';
+            if (*c == '-' || *c == '+') c++;
+            if (c == e || e - c > 18) throw bad(what);
+            long v = 0;
+            for (; c < e; c++) {
+                const unsigned d = unsigned(*c) - unsigned('0');
+                if (d > 9) throw bad(what);
+                v = v * 10 + long(d);
+            }
+            return neg ? -v : v;
         };
-        const std::string tag(tok[0].first, tok[0].second);
-        if (tag == "W") {
+        const char tag = tok[0].second == 1 ? tok[0].first[0] : '?';
+        if (tag == 'W') {
             WindowHaplotypes w;
             w.index = int(integer(1, "Cannot read window record"));
             w.leftPos = uint32_t(integer(2, "Cannot read window record")); w.rightPos = uint32_t(integer(3, "Cannot read window record"));
             out.push_back(w);
             cur = &out.back();
-        } else if (tag == "H") {
+        } else if (tag == 'H') {
             if (!cur || tok.size() < 2) throw bad("Cannot read haplotype record");
             cur->haps.push_back(Haplotype(std::string(tok[1].first, tok[1].second)));
-        } else if (tag == "A") {                                       // the haplotype's own alignment to the reference: one number per base
+        } else if (tag == 'A') {                                       // the haplotype's own alignment to the reference: one number per base
             if (!cur || cur->haps.empty()) throw bad("Cannot read haplotype alignment record");
             std::vector<int> &v = cur->haps.back().refHpos;
-            v.clear();
-            for (size_t k = 1; k < tok.size(); k++) v.push_back(int(integer(k, "Cannot read haplotype alignment record")));
-        } else if (tag == "V") {
+            v.resize(tok.size() - 1);
+            for (size_t k = 1; k < tok.size(); k++) v[k - 1] = int(integer(k, "Cannot read haplotype alignment record"));
+        } else if (tag == 'V') {
             const char *what = "Cannot read variant record";
             if (!cur || cur->haps.empty() || tok.size() < 12) throw bad(what);
-            const std::string kind(tok[1].first, tok[1].second), str(tok[3].first, tok[3].second);
+            const char kind = tok[1].second == 1 ? tok[1].first[0] : '?';
+            const std::string str(tok[3].first, tok[3].second);
             const int key = int(integer(2, what));
             int v[8];
             for (size_t k = 0; k < 8; k++) v[k] = int(integer(4 + k, what));
             AlignedVariant av(str, v[0], v[1], v[2], v[3]);
             av.setFlanking(v[4], v[5], v[6], v[7]);
-            if (kind == "I") cur->haps.back().indels[key] = av;
-            else if (kind == "S") cur->haps.back().snps[key] = av;
+            if (kind == 'I') cur->haps.back().indels[key] = av;
+            else if (kind == 'S') cur->haps.back().snps[key] = av;
             else throw bad("Variant record must say I or S");
         } else throw bad("Unknown record");
     }

@@ -19,7 +19,8 @@ def _flip(seq):
 
 class Fetcher:
     def __init__(self, records, max_reads=10000, max_read_length=500, min_read_overlap=20, map_unmapped=False, map_qual_threshold=0.99, max_insert=2000):
-        self.records = records                                                     # one chromosome, sorted by pos
+        # one chromosome; either one list of records sorted by pos, or one such list per BAM pool (the reference's myBams)
+        self.pools = records if records and isinstance(records[0], list) else [records]
         self.p = dict(maxReads=max_reads, maxReadLength=max_read_length, minReadOverlap=min_read_overlap, mapUnmapped=map_unmapped, thr=map_qual_threshold)
         self.max_insert = max_insert
         self.buffer, self.old_left, self.old_right_fetch, self.reset = [], 0, 0, True
@@ -31,7 +32,9 @@ class Fetcher:
         beg, end = beg - U32 if beg >= 1 << 31 else beg, end - U32 if end >= 1 << 31 else end     # the int arguments of bam_fetch
         if beg >= end:
             return []
-        return [r for r in self.records if _end(r) > beg and r["pos"] < end and not (r["flag"] & (1024 | 512 | 2048))]
+        # pool after pool into one vector (DInDel.cpp:981-993), each record remembering its pool (Read::poolID)
+        return [(b, r) for b, records in enumerate(self.pools) for r in records
+                if _end(r) > beg and r["pos"] < end and not (r["flag"] & (1024 | 512 | 2048))]
 
     def get_reads(self, left, right):
         p = self.p
@@ -44,7 +47,7 @@ class Fetcher:
             self.buffer = []
             self.old_right_fetch = right_fetch
         else:
-            self.buffer = [r for r in self.buffer if not (r["pos"] % U32 < left_most)]
+            self.buffer = [(b, r) for b, r in self.buffer if not (r["pos"] % U32 < left_most)]
             if left_most < self.old_right_fetch:
                 left_fetch = self.old_right_fetch
         if left_fetch <= right_fetch:
@@ -52,15 +55,15 @@ class Fetcher:
             if len(self.buffer) + len(new) > p["maxReads"] * 100:
                 raise ValueError("Too many reads in region")
             self.old_right_fetch = right_fetch
-            self.buffer += [r for r in new if r["pos"] % U32 >= left_fetch]
+            self.buffer += [(b, r) for b, r in new if r["pos"] % U32 >= left_fetch]
         count = {}
-        for r in self.buffer:
+        for _b, r in self.buffer:
             count[r["qname"]] = count.get(r["qname"], 0) + 1
             if count[r["qname"]] > 2:
                 raise ValueError("duplicate reads!")
-        reads = [dict(rec=r, qname=r["qname"], pos=r["pos"], size=len(r["seq"]), seq=r["seq"], mapQual=1.0 - 10.0 ** (-r["mapq"] / 10.0), matePos=r["mpos"], mateLen=-1,
+        reads = [dict(rec=r, pool=b, qname=r["qname"], pos=r["pos"], size=len(r["seq"]), seq=r["seq"], mapQual=1.0 - 10.0 ** (-r["mapq"] / 10.0), matePos=r["mpos"], mateLen=-1,
                       unmapped=bool(r["flag"] & 4), mateUnmapped=bool(r["flag"] & 8), paired=bool(r["flag"] & 1), reverse=bool(r["flag"] & 16), end=_end(r))
-                 for r in self.buffer]
+                 for b, r in self.buffer]
         for x in reads:
             x["mapQual"] = min(max(x["mapQual"], 1e-16), 1.0 - 1e-16)              # Read.hpp:127-131
         mapped, unmapped = {}, {}
@@ -125,17 +128,19 @@ class Fetcher:
         return out
 
 
-def run_windows(records, windows, **kw):
-    """What the hook ddh_get_reads_json reports for consecutive windows: per window {"throw": msg} or the selected reads."""
+def run_windows(records, windows, with_buffer=False, **kw):
+    """What the hook ddh_get_reads_json reports for consecutive windows: per window {"throw": msg} or the selected reads.
+    with_buffer: (outcome, [(qname, pool) of the buffer in order]) per window, the selected reads carrying their pool."""
     f = Fetcher(records, **kw)
     res = []
     for left, right in windows:
         skipped = False
         try:
             got = f.get_reads(left, right)
-            res.append([(x["qname"], x["pos"], x["mapQual"], x["matePos"], x["mateLen"], int(x["unmapped"]), x["seq"]) for x in got])
+            out = [(x["qname"], x["pos"], x["mapQual"], x["matePos"], x["mateLen"], int(x["unmapped"]), x["seq"]) + ((x["pool"],) if with_buffer else ()) for x in got]
         except ValueError as e:
-            res.append({"throw": str(e)})
+            out = {"throw": str(e)}
             skipped = True
+        res.append((out, [(r["qname"], b) for b, r in f.buffer]) if with_buffer else out)
         f.window_done(skipped, left)
     return res

@@ -28,6 +28,7 @@ def lib():
     L = hostlib.load()
     L.ddh_bam_fetch_json.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.ddh_parse_inputs_json.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.ddh_get_reads_pools_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.ddh_get_reads_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_char_p, C.c_int]
     return L
 
@@ -265,6 +266,50 @@ def test_get_reads_against_the_python_restatement(lib, tmp_path, map_unmapped):
             assert [x[2] for x in g] == pytest.approx([x[2] for x in e], rel=0, abs=0), (w, windows[w])
             assert sorted(g) == sorted(e), (w, windows[w])
         assert n_ok >= 5 and any(isinstance(e, dict) for e in want)
+
+
+def test_two_bam_pools_buffer_order_and_selection(lib, tmp_path):
+    """--bamFiles: two files as pools of one read buffer (DInDel.cpp:976-1003, Read::fetchFuncVectorPooled).  The buffer's order — the
+    survivors of the windows before, then each pool's new records — depends on the windows walked so far; after every window it and the
+    selection (with poolID) equal tests/_getreads_oracle.py extended to pools.  A one-line list is the single-file result."""
+    from tests import _getreads_oracle as go
+    rng = np.random.default_rng(5)
+    n_ref = 40000
+    scene = _pairs_scene(rng, n_ref)
+    pools = [[], []]
+    by_name = {}
+    for r in scene:                                                        # mates stay in one file
+        pools[by_name.setdefault(r["qname"], int(rng.integers(0, 2)))].append(r)
+    paths = []
+    for k, recs in enumerate(pools):
+        paths.append(str(tmp_path / ("pool%d.bam" % k)))
+        bw.write_bam(paths[-1], "@SQ\tSN:20\tLN:%d\n" % n_ref, [("20", n_ref)], [(0, r) for r in recs])
+    windows, left = [], 3000
+    while left < n_ref - 2000:
+        windows.append((left, left + int(rng.integers(60, 200))))
+        left += int(rng.choice([0, 30, 150, 400, 900, 2500, 5000]))
+    flat = (C.c_int * (2 * len(windows)))(*[v for w in windows for v in w])
+    for max_reads, thr in ((10000, 0.99), (14, 0.5)):                      # the second: windows skipped (above_read_count_threshold) reset the buffer
+        prm = (C.c_int * 4)(max_reads, 500, 20, 1)
+        got = call_json(lib.ddh_get_reads_pools_json, "\n".join(paths).encode(), b"", b"20", flat, len(windows), prm, thr, b"", 1, cap=1 << 27)
+        want = go.run_windows(pools, windows, with_buffer=True, max_reads=max_reads, map_unmapped=True, map_qual_threshold=thr)
+        n_ok = n_thrown = 0
+        for w, (g, (e, buf)) in enumerate(zip(got, want)):
+            assert [tuple(x) for x in g["buffer"]] == buf, (w, windows[w])
+            if isinstance(e, dict):
+                assert g["throw"] == e["throw"], (w, windows[w])
+                n_thrown += 1
+                continue
+            rows = [(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[8]) for x in g["reads"]]
+            assert [x[2] for x in rows] == [x[2] for x in e], w                  # mapping qualities descending, as selected
+            assert sorted(rows) == sorted(e), (w, windows[w])                      # ties of one mapping quality: as sets (std::sort's order)
+            n_ok += 1
+        assert n_ok > 5 and (max_reads > 100 or n_thrown >= 2)
+        assert any(len({b for _q, b in buf}) == 2 and [b for _q, b in buf] != sorted(b for _q, b in buf) for _e, buf in want)   # orders that are not pool-major occur
+    # one pool given as a list of one file: the single-file hook's result
+    prm = (C.c_int * 4)(10000, 500, 20, 1)
+    one = call_json(lib.ddh_get_reads_pools_json, paths[0].encode(), b"", b"20", flat, len(windows), prm, 0.99, b"", 0, cap=1 << 27)
+    assert one == call_json(lib.ddh_get_reads_json, paths[0].encode(), b"", b"20", flat, len(windows), prm, 0.99, cap=1 << 27)
 
 
 def test_fetches_on_one_handle_match_fresh_ones(lib, tmp_path):

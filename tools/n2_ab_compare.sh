@@ -16,7 +16,7 @@ for model in "" "--faster"; do
     "$R/dindel_tgi_amd/host/dindel_gpu" $args --outputFile "$D/cur_$tag" $model 2>/dev/null || { echo "current driver failed ($tag)"; exit 1; }
     e=$(date +%s.%N)
     echo "$tag current: $(python3 -c "print(round($e - $s, 3))") s, $(wc -l < "$D/cur_$tag.glf.txt") lines"
-    for old in "$R"/tools/_ab/*_host; do
+    for old in ${AB_DIRS:-"$R"/tools/_ab/*_host}; do        # AB_DIRS="dir ...": only these revisions
         [ -d "$old" ] || continue
         bin=$(ls "$old"/dindel_gpu_* 2>/dev/null | head -1)
         [ -n "$bin" ] || continue
