@@ -639,7 +639,13 @@ int ddh_fixture_json(const char *path, const int *indices, int n, char *out, int
                         first = false;
                     }
                 }
-                os << "]]";
+                os << "]";
+                if (!w->haps[h].refHpos.empty()) {                  // the A record (hap.ml.hpos), when the file carries one
+                    os << ",[";
+                    for (size_t b = 0; b < w->haps[h].refHpos.size(); b++) os << (b ? "," : "") << w->haps[h].refHpos[b];
+                    os << "]";
+                }
+                os << "]";
             }
             os << "]]";
         }
