@@ -663,10 +663,15 @@ static int waves_for_reads(int64_t units, int maxw)
 }
 
 // Read split of a haplotype over workgroups.  One workgroup per haplotype is the cheapest (the per-haplotype setup is done
-// once), but a small batch has too few haplotypes to fill the chip, and a split that leaves the workgroup's `waves` waves a
-// ragged number of rounds wastes wave slots (tools/batch_size_sweep.py).  Take the smallest split that yields `min_blocks`
-// workgroups with >= 90 % of the wave slots used; failing that, the best-filled split at or above the needed one.
-static int64_t pick_split(int64_t n_haps, int64_t units, int waves, int64_t min_blocks)
+// once), but a small batch has too few haplotypes to fill the chip, a split that leaves the workgroup's `waves` waves a
+// ragged number of rounds wastes wave slots (tools/batch_size_sweep.py), and a grid that is only a few times what the chip
+// holds at once (`resident` workgroups) ends with a partly filled last round.  Among the splits from the one that yields
+// `min_blocks` workgroups up to 8 x that, take the one with the best product of wave-slot use, round fill and setup
+// amortisation (the per-haplotype tables cost about a quarter of one read's work per wave); within 1 % the smaller split
+// wins.  Measured against the rule without the round term (DD_SPLIT_NO_ROUNDS=1, profiles/r03/split_ab.txt): 128 windows
+// +4.6 %, 512 windows +1.8 %, the other sizes within 0.5 % — workgroups do not finish in lock step, so the rounds matter
+// less than the count suggests.  resident == 0: the rounds are not modelled (the --faster kernel's callers).
+static int64_t pick_split(int64_t n_haps, int64_t units, int waves, int64_t min_blocks, int64_t resident = 0)
 {
     if (units < 1) units = 1;
     if (n_haps < 1) n_haps = 1;
@@ -674,13 +679,28 @@ static int64_t pick_split(int64_t n_haps, int64_t units, int waves, int64_t min_
     int64_t need = (min_blocks + n_haps - 1) / n_haps;
     if (need < 1) need = 1;
     if (need > max_split) need = max_split;
+    if (resident <= 0) {
+        int64_t best = need;
+        double bestu = -1.0;
+        for (int64_t sp = need; sp <= max_split; sp++) {
+            const int64_t slots = sp * waves;
+            const double u = (double)units / (double)(slots * ((units + slots - 1) / slots));
+            if (u >= 0.9) return sp;
+            if (u > bestu) { bestu = u; best = sp; }
+        }
+        return best;
+    }
     int64_t best = need;
-    double bestu = -1.0;
-    for (int64_t sp = need; sp <= max_split; sp++) {
+    double beste = -1.0;
+    const int64_t last = std::min<int64_t>(max_split, need * 8);
+    for (int64_t sp = need; sp <= last; sp++) {
         const int64_t slots = sp * waves;
-        const double u = (double)units / (double)(slots * ((units + slots - 1) / slots));
-        if (u >= 0.9) return sp;
-        if (u > bestu) { bestu = u; best = sp; }
+        const double per_wave = (double)((units + slots - 1) / slots);          // reads of the busiest wave: the workgroup's duration
+        const double use = (double)units / ((double)slots * per_wave);
+        const int64_t n = n_haps * sp;
+        const double fill = (double)n / (double)(((n + resident - 1) / resident) * resident);
+        const double e = use * fill * per_wave / (per_wave + 0.25);
+        if (e > beste * 1.01) { beste = e; best = sp; }
     }
     return best;
 }
@@ -837,7 +857,10 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     if (lc && lc->hap_list) { hap_begin = lc->list_begin; hap_end = lc->list_end; }   // positions in the class list
     // the split is chosen for the haplotypes THIS launch covers: a rare length class or a small window block must still
     // spread over the chip
-    const int64_t split = pick_split(hap_end - hap_begin, avg_reads, waves, target_blocks);
+    // workgroups the chip holds at once (one-shot grids; a persistent GBT grid is capped to that number below anyway)
+    int64_t resident = 256 * (int64_t)std::max(1, std::min((int)((160u * 1024u) / (lds ? lds : 1)), pl.waves_per_cu / waves));
+    if (getenv("DD_SPLIT_NO_ROUNDS")) resident = 0;                            // A/B only: the rule before round 3
+    const int64_t split = pick_split(hap_end - hap_begin, avg_reads, waves, target_blocks, resident);
     A.n_split = (int32_t)split;
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.item_begin = (int32_t)(hap_begin * split);
@@ -875,8 +898,9 @@ int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qu
     if ((rc = make_plan(p, max_hap_len, max_read_len, n_qual, pl, A))) return rc;
     const int waves = waves_for_reads(avg_reads, pl.waves);
     out[0] = pl.K; out[1] = pl.Dt; out[2] = pl.gbt ? 1 : 0; out[3] = waves;
-    out[4] = (int32_t)pick_split(n_haps, avg_reads, waves, 4096);
     out[5] = (int32_t)lds_layout(pl.K, pl.Dt, max_read_len, n_qual, waves, pl.gbt, A);
+    out[4] = (int32_t)pick_split(n_haps, avg_reads, waves, 4096,
+                                 256 * (int64_t)std::max(1, std::min((int)((160u * 1024u) / (out[5] > 0 ? (unsigned)out[5] : 1u)), pl.waves_per_cu / waves)));
     out[6] = (int32_t)((pl.scratch_bytes >> 10) & 0x7fffffff);
     out[7] = pl.waves_per_cu;
     return DD_SUCCESS;

@@ -268,6 +268,7 @@ int main(int argc, char **argv)
         const double t_setup = seconds_since(t_start);
 
         long nWindows = 0, nSkipped = 0;
+        std::vector<std::pair<double, long> > progress;                          // (seconds since start, windows written) after every batch
         double t_reduce_work = 0.0, t_prepare = 0.0, t_compute = 0.0, t_pack = 0.0, t_device = 0.0, t_unpack = 0.0, t_reduce = 0.0;
         std::mutex fatal_m, done_m;
         std::condition_variable done_cv;
@@ -450,6 +451,7 @@ int main(int argc, char **argv)
                         nWindows++;
                     }
                     glfOutput.flush();
+                    progress.push_back(std::make_pair(seconds_since(t_start), nWindows));
                     // the haplotypes of these windows can go: noted here, dropped by the prepare worker that takes the batch next
                     // (side by side with the others, not in this thread's serial part)
                     for (size_t i = 0; i < B.tasks.size(); i++) if (B.tasks[i].haps) { B.toRelease.push_back(B.tasks[i].index); B.tasks[i].haps = NULL; }
@@ -519,7 +521,10 @@ int main(int argc, char **argv)
                     Batch::Before W = { T.tid, T.fileLeftPos, T.fileRightPos };
                     recent.push_back(W);
                 }
-                if (int(nTasks) >= batchWindows && !flush()) break;
+                // the first batches are small (an eighth, a quarter, half of --batchWindows): the GPU gets its first windows while the bulk is
+                // still being prepared, and the writer its first lines
+                const int want = seq >= 3 ? batchWindows : std::max(1, batchWindows >> (3 - int(seq)));
+                if (int(nTasks) >= want && !flush()) break;
             }
             if (nTasks) flush();
         } catch (std::string &s) { fail(s); }
@@ -546,7 +551,13 @@ int main(int argc, char **argv)
                 while (std::getline(st, line)) if (line.compare(0, 6, "VmHWM:") == 0) peakKb = atol(line.c_str() + 6);
             }
             std::cout << "timing: wall=" << wall << " setup=" << t_setup << " prepare_threads=" << prepareThreads << " prepare=" << t_prepare << " compute_threads=" << computeThreads << " compute=" << t_compute << " (pack=" << t_pack
-                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce_threads=" << reduceThreads << " reduce=" << t_reduce << " (work=" << t_reduce_work << " summed over the threads)" << " peak_rss_mb=" << peakKb / 1024 << " windows_per_s=" << double(nWindows) / wall << std::endl;
+                      << " device=" << t_device << " unpack=" << t_unpack << ") reduce_threads=" << reduceThreads << " reduce=" << t_reduce << " (work=" << t_reduce_work << " summed over the threads)" << " peak_rss_mb=" << peakKb / 1024 << " windows_per_s=" << double(nWindows) / wall;
+            // the rate once the pipeline is full: from the batch that completed the first fifth of the windows to the last one
+            size_t from = 0;
+            while (from + 1 < progress.size() && progress[from].second * 5 < nWindows) from++;
+            if (from + 1 < progress.size() && progress.back().first > progress[from].first)
+                std::cout << " steady_windows_per_s=" << double(progress.back().second - progress[from].second) / (progress.back().first - progress[from].first);
+            std::cout << std::endl;
         }
     } catch (std::string &s) {
         std::cerr << "Exception: " << s << std::endl;

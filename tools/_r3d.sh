@@ -5,4 +5,4 @@ export LD_LIBRARY_PATH=$PWD/dindel_tgi_amd/csrc:$(python3 -c 'import os, torch; 
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- $R/dindel_tgi_amd/host/dindel_gpu --bamFile /tmp/n2b/reads.bam --varFile /tmp/n2b/windows.txt --hapFile /tmp/n2b/haps.txt --outputFile /tmp/n2b/tl --timing --quiet > $R/gpurun_out/r3d/run.txt 2>&1
-python3 $R/tools/pipeline_timeline.py /tmp/tl > $R/gpurun_out/r3d/timeline.txt 2>&1
+python3 $R/tools/pipeline_timeline.py /tmp/tl 1000 1060 > $R/gpurun_out/r3d/timeline.txt 2>&1

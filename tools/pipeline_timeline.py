@@ -42,3 +42,11 @@ for t, k in ev:
     depth += k
     last = t
 print("two or more kernels in flight: %.1f ms" % (two / 1e6))
+if len(sys.argv) > 2:                                    # a slice of the timeline, one line per kernel: python3 tools/pipeline_timeline.py DIR FROM_MS TO_MS
+    lo, hi = float(sys.argv[2]) * 1e6 + t0, float(sys.argv[3]) * 1e6 + t0
+    print("columns:", ",".join(rows[0].keys()))
+    for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if lo <= s <= hi:
+            print("%10.3f %10.3f ms  q=%s  %s  grid=%s wg=%s" % ((s - t0) / 1e6, (e - t0) / 1e6, r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][:40],
+                                                            r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?"))))
