@@ -281,6 +281,7 @@ struct DevBuf {
 static thread_local int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per host thread, like the cache and the error string
 static thread_local char g_kernel_name[64] = "dd_hmm_kernel";
 static thread_local int g_last_direct = 0;     // output arrays the last host-pointer call on this thread let the kernels write in place
+static thread_local int g_last_fold = 0;       // the last main-model launch used the FOLD build (hmm_kernel.hip)
 
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
@@ -294,7 +295,7 @@ const char *dd_last_error(void) { return g_err.c_str(); }
 const char *dd_kernel_name(void)
 {   // the template instance this host thread launched last, as rocprofv3 prints it (inside "void ddk::...(ddk::KernelArgs)")
     const int K = g_last_launch[0], D = g_last_launch[1];
-    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s>", K, D % 100, D >= 100 ? "true" : "false");
+    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s, %s>", K, D % 100, D >= 100 ? "true" : "false", g_last_fold ? "true" : "false");
     else if (K > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_faster_kernel");
     return g_kernel_name;
 }
@@ -880,7 +881,11 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, A, (unsigned)grid, waves, lds, st));
+    // the build with the end states folded into the generic candidate code (hmm_kernel.hip, FOLD): K <= 2, D build 6, LDS
+    // back-pointers, and every haplotype of this launch leaves three idle positions (numS <= 64 K - 3)
+    const bool fold = !pl.gbt && Dt == 6 && K <= 2 && 64 * K >= cls_hap + 5 && !getenv("DD_NO_FOLD");
+    g_last_fold = fold ? 1 : 0;
+    HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, fold, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ && (!lc || lc->run_onhap)) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
 }

@@ -178,7 +178,9 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
 // tile is written once per read base (coalesced, one word per lane) and read back by the scalar traceback;
 // a few tens of MB for the whole chip, so it lives in L2 / Infinity Cache.
-template <int K, int D, bool GBT>
+// FOLD: the right->middle pass runs its LO / RO end states inside the generic candidate code (see foldRO in the body); built
+// for the LDS builds with K <= 2, D = 6 only (the other builds lose more to the extra stores than the blocks cost them).
+template <int K, int D, bool GBT, bool FOLD = false>
 __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT)) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,6 +191,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 1..4 waves (host picks what fits LDS best)
     const int NP = 64 * K;
+    constexpr bool foldLO = FOLD;                   // (host: only for haplotypes with numS <= NP - 3)
     const int Dr = P.D;                             // real D (== D unless the generic D=12 build is used)
     const double *T = P.tables;
     const double lLL = T[TC_LLL], lFL = T[TC_LFL], II = T[TC_II], NI = T[TC_NI], NN = T[TC_NN];
@@ -306,6 +309,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         }
         for (int i = tid; i < D; i += nthr) shY[i] = (i + 1 > Dr) ? NEG_INF : (double)i * II;   // y = i+1; jumps past the real D are off
         __syncthreads();
+        // the end states riding in the generic code (see foldLO / foldRO below): their candidate constants
+        if (foldLO) {
+            for (int y = 1 + tid; y <= D; y += nthr) {
+                shC[((K - 1) * D + y - 1) * 64 + 63] = y == 2 ? lLL : (y == 3 ? lFL : NEG_INF);
+                if (RO - (RO / K) * K == K - 1) shC[((K - 1) * D + y - 1) * 64 + RO / K] = y == 2 ? 0.0 : NEG_INF;
+            }
+            __syncthreads();
+        }
     }
     // ---- per-lane register constants for this haplotype (states past RO are switched off with -inf) ----
     const int x0 = lane * K;
@@ -325,6 +336,38 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         mOwn[k] = !valid ? 0u : (scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u));
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
+    // Right->middle pass: the two end states ride in the generic candidate code instead of running as one-lane blocks of their
+    // own (13 + 8 fp64 and 7 + 5 32-bit wave instructions per read base, a fifth of that pass's sweep).
+    //   * LO moves from position 0 to the idle position NP-1 (lane 63's last slot), whose jump candidates read the pad slots
+    //     NP, NP+1, NP+2.  Those carry what the LO recurrence (:1720-1722, :1746-1749, :1762) needs, so that the generic forms
+    //     (c_y + v) + ov, (eq + in) + eInc and (ov + v) + NI evaluate the reference's sums term by term:
+    //       slot NP   {beta[LO], eq}            y = 1 switched off (c = -inf); read by the inserted state:  (eq + beta[LO]) + NI
+    //       slot NP+1 {eq + beta[LO], NN}       y = 2, c = lLL:   ((eq + beta[LO]) + lLL) + NN             -> stays LO      (idx 0)
+    //       slot NP+2 {ov1 + beta[1], NN}       y = 3, c = lFL:   ((obs[1] + beta[1]) + lFL) + NN          -> base 1        (idx 1)
+    //       insertion edge with eInc = E[1]:    (eq + beta[numS]) + E[1]                                     -> numS          (idx numS)
+    //     (x + y is commutative and the association is kept; y >= 2 and the insertion edge use the same "> best + EPS" rule the LO
+    //     block used; y = 1 leaves best = -inf, which the first real candidate always beats.)
+    //   * RO, when it sits in its lane's last slot (kRO == K-1: its candidates then come from LDS, not from the lane's own
+    //     registers), gets {beta[RO], eq} into slot RO+1 and {eq + beta[RO], Nn[RO]} into slot RO+2, c_2 = 0, eInc = 0:
+    //       y = 2: (0 + (eq + beta[RO])) + Nn[RO]   -> stays RO;   insertion edge: (eq + beta[numS+RO]) + 0   -> numS+RO   (:1741-1742, :1750)
+    //   Needs the positions NP-3 .. NP-1 idle (numS <= NP-3), so that RO's two slots and LO's position do not collide: the host
+    //   launches the FOLD build only for length classes with 64 K >= Hs + 5 (launch_class, capi.cpp).
+    //   What it buys: the one-lane blocks are 19 of the sweep's 89 fp64 instructions but run with one lane enabled, and a
+    //   sparse EXEC mask costs far less than a full wave instruction — the fold is worth 2-3 % at K <= 2 / D = 6 (245.8 ->
+    //   240.3 ms per 6,000 windows of configs[1]) and nothing or less where the sweep is longer (profiles/r03/fold_ab.txt).
+    const bool foldRO = foldLO && kRO == K - 1;
+    constexpr int k1 = 1 % K;                       // state 1 lives in lane 1 / K, slot k1
+    const int lane1 = 1 / K;
+    if (foldLO && lane == 63) eInc[K - 1] = E_1;
+    if (foldRO && lane == laneRO) eInc[K - 1] = 0.0;
+    // where this lane stores for its end state: lane 63 (LO) slots NP / NP+1, lane laneRO (RO, when folded) slots RO+1 / RO+2;
+    // the owner of state 1 stores obs[1] + beta[1] into slot NP+2
+    const bool isEnd = foldLO && (lane == 63 || (foldRO && lane == laneRO));
+    double *rowAd = reinterpret_cast<double *>(rowA);
+    double *endA = rowAd + 2 * (lane == 63 ? (0 % K) * AQ + PADQ + 64 + 0 / K : 0 * AQ + PADQ + laneRO + 1);
+    double *endV = rowAd + 2 * (lane == 63 ? (1 % K) * AQ + PADQ + 64 + 1 / K : (1 % K) * AQ + PADQ + laneRO + 1 + 1 / K);
+    double *oneV = rowAd + 2 * ((2 % K) * AQ + PADQ + 64 + 2 / K);
+    const double endC = (lane == 63) ? NN : Nn_RO;
 
     const int64_t pair_base = P.win_pair_off[w] + (int64_t)(g - h0) * R;
     const int rs_base = P.read_seq_off[r0];
@@ -391,6 +434,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             const int kk = i / (2 * PADQ), j = i - kk * (2 * PADQ);
             rowA[kk * AQ + (j < PADQ ? j : 64 + j)] = make_double2(NEG_INF, 0.0);
         }
+        if constexpr (foldLO) {          // constant halves of the end states' slots (the changing halves are stored per read base)
+            if (lane == lane1) oneV[1] = NN;
+        }
         STAMP(1);   // bMid + staging
         double a[K], in[K];           // current slice: "on base x" and "inserted at x"
         // ================= right -> middle: passMessageTwoInc for b = L-1..bMid+1 (:1576-1578, :1715-1773)
@@ -413,7 +459,15 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                         cInc[k][y - 1] = (src <= RO && y <= Dr) ? lp + Ns : NEG_INF;
                     }
                 }
+                if (foldLO) {
+#pragma unroll
+                    for (int y = 1; y <= D; y++) {
+                        if (lane == 63) cInc[K - 1][y - 1] = y == 2 ? lLL : (y == 3 ? lFL : NEG_INF);
+                        if (foldRO && lane == laneRO) cInc[K - 1][y - 1] = y == 2 ? 0.0 : NEG_INF;
+                    }
+                }
             }
+            if (foldLO && lane == 63) { a[K - 1] = 0.0; in[K - 1] = 0.0; }      // beta[L-1][LO] = beta[L-1][numS] = 0, at LO's position in this pass
             auto cinc = [&](int k, int y) -> double {       // y = 1..D
                 if constexpr (LEAN) return shC[(k * D + y - 1) * 64 + lane]; else return cInc[k][y - 1];
             };
@@ -426,6 +480,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                     ov[k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
                     v[k] = a[k];
                     rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[k]);
+                }
+                if constexpr (foldLO) {                            // what the end states' generic candidates read (after the owners' own slots)
+                    // 8-byte stores (RO's two slots are ordinary positions whose owner has just stored its own pair there: both halves are
+                    // rewritten; LO's slot NP+2 is a pad, its constant half was stored when the read began)
+                    if (isEnd) { endA[0] = a[K - 1]; endA[1] = eq; endV[0] = eq + a[K - 1]; endV[1] = endC; }
+                    if (lane == lane1) oneV[0] = ov[k1] + a[k1];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -462,7 +522,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                     ni[k] = dmax(d, val);
                     btb[k] = ch | (take ? ((btacc_t)(1u << BP::CB) << sh) : (btacc_t)0);
                 }
-                if (lane == 0) {                                    // x = 0 (:1720-1722, :1746-1749, :1762)
+                if constexpr (!foldLO) if (lane == 0) {             // x = 0 (:1720-1722, :1746-1749, :1762)
                     double best = ((eq + a[0]) + lLL) + NN;         // idx 0
                     unsigned code = 0;
                     const double c2 = ((ov[1] + v[1]) + lFL) + NN;  // idx 1
@@ -480,7 +540,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                     ni[0] = dmax(d, val);
                     btb[0] = (btacc_t)(code | (take ? (1u << BP::CB) : 0u));
                 }
-                if (lane == laneRO) {                               // x = RO (:1741-1742, :1750, :1763-1767)
+                if (!foldRO && lane == laneRO) {                    // x = RO (:1741-1742, :1750, :1763-1767)
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         if (k == kRO) {
@@ -511,6 +571,11 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         double be_a[K], be_i[K];           // beta[bMid]
 #pragma unroll
         for (int k = 0; k < K; k++) { be_a[k] = a[k]; be_i[k] = in[k]; }
+        if (foldLO) {                      // LO's beta back to position 0, where the join and the left->middle pass have it
+            const double tA = __shfl(a[K - 1], 63), tI = __shfl(in[K - 1], 63);
+            if (lane == 0) { be_a[0] = tA; be_i[0] = tI; }
+            if (lane == 63) { be_a[K - 1] = NEG_INF; be_i[K - 1] = NEG_INF; }
+        }
 
         // The left->middle chain of RO / numS+RO is a sink: nothing else in that pass reads it, and it only matters
         // if a state with prior -100 wins the join.  Every alpha, beta, emission and transition term is <= 0, so those
@@ -771,12 +836,16 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 int ins = s0 >= numS ? 1 : 0, x = s0 - (ins ? numS : 0), b = bMid;
                 while (b < L - 1) {
                     unsigned f;
+                    // where this pass kept the state's back-pointer field, and the code that means "stays": LO folded into the generic
+                    // code sits at position NP-1 and stays with y = 2 (as does a folded RO); the one-lane blocks use code 0
+                    const int xf = (foldLO && x == 0) ? NP - 1 : x;
+                    const unsigned stayCode = (x == 0 ? foldLO : foldRO) ? 2u : 0u;
                     if (!ins) {
                         const int left = L - 1 - b, maxrun = left < 64 ? left : 64;
-                        const bool stay = (x == 0 || x == RO);             // LO / RO: code 0 = stays
+                        const bool stay = (x == 0 || x == RO);             // LO / RO
                         const bool valid = lane < maxrun && (stay || x + lane <= Hs);
-                        f = valid ? fieldAt(b + 1 + lane, stay ? x : x + lane) : 0u;
-                        const unsigned long long m = __ballot(valid && (f & chmask) == (stay ? 0u : 1u));
+                        f = valid ? fieldAt(b + 1 + lane, stay ? xf : x + lane) : 0u;
+                        const unsigned long long m = __ballot(valid && (f & chmask) == (stay ? stayCode : 1u));
                         const int run = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
                         if (lane < run) ms[b + 1 + lane] = (int16_t)(stay ? x : x + 1 + lane);
                         b += run;
@@ -786,15 +855,19 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                         if (!stay && x > Hs) continue;                     // the diagonal ran into RO: next round handles it as a stay run
                         f = (unsigned)__builtin_amdgcn_readlane((int)f, run);
                     } else {
-                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b + 1, x));
+                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b + 1, xf));
                     }
                     // on base x: ch = jump length y (to x+y), 0 = to the inserted state numS+x; LO: 0 LO, 1 base 1, 2 numS;
-                    // RO: 0 RO, else numS+RO.  inserted at x: bit set = leaves to min(x+1, RO) (LO's stays LO), else stays
+                    // RO: 0 RO, else numS+RO.  inserted at x: bit set = leaves to min(x+1, RO) (LO's stays LO), else stays.
+                    // Folded end states carry generic codes: 0 = to the inserted state, 2 = stays, LO's 3 = base 1.
                     const int ch = (int)(f & chmask), ib = (int)(f >> BP::CB);
                     const int z = ch == 0 ? 1 : 0;
                     int gx = x + ch, gi = z;
-                    if (x == RO) { gx = RO; gi = z ^ 1; }
-                    if (x == 0) { gx = ch & 1; gi = ch >> 1; }
+                    if (x == RO) { gx = RO; gi = foldRO ? z : (z ^ 1); }
+                    if (x == 0) {
+                        if (foldLO) { gx = ch == 3 ? 1 : 0; gi = z; }
+                        else { gx = ch & 1; gi = ch >> 1; }
+                    }
                     if (ins) {
                         int lx = x + 1 > RO ? RO : x + 1;
                         if (x == 0) lx = 0;
@@ -989,7 +1062,7 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
 }
 #endif
 
-template <int K, int D, bool GBT>
+template <int K, int D, bool GBT, bool FOLD = false>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
     // The cap on dynamic LDS is a property of the function, not of a launch: it is raised ONCE per template instance (and
@@ -1001,26 +1074,27 @@ static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t l
     if (e != hipSuccess) return e;
     const unsigned bit = 1u << (dev & 31);
     if (!(raised.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT, FOLD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_release);
     }
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT>), grid, dim3(waves * 64), lds, st, A);
+    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT, FOLD>), grid, dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }
 
 #ifdef DD_ONLY_K   // diagnostic builds: a single (K, D) compiles in seconds
-hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
     if (K != DD_ONLY_K || Dt != DD_ONLY_D) return hipErrorInvalidValue;
+    if (fold && !gbt) return launch_one<DD_ONLY_K, DD_ONLY_D, false, true>(A, dim3(grid), waves, lds, st);
     return gbt ? launch_one<DD_ONLY_K, DD_ONLY_D, true>(A, dim3(grid), waves, lds, st)
                : launch_one<DD_ONLY_K, DD_ONLY_D, false>(A, dim3(grid), waves, lds, st);
 }
 #else
 // The product library instantiates K = 1..12 positions per lane x the D builds 6 / 11 / 12 x {LDS, HBM-scratch} back-pointers:
-// 72 kernels.  The file is compiled once per D build (-DDD_INST_D=6|11|12, see the Makefile) so that they build in parallel;
+// 72 kernels, plus the FOLD variants of the K = 1 and K = 2 LDS builds at D = 6.  The file is compiled once per D build (-DDD_INST_D=6|11|12, see the Makefile) so that they build in parallel;
 // the D = 6 unit also carries the dispatcher and the small kernels.
 template <int D, bool GBT>
 static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
@@ -1045,12 +1119,14 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
 #ifndef DD_INST_D
 #define DD_INST_D 0            // 0: every D build in this unit
 #endif
-hipError_t launch_hmm_d6(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d11(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 #if DD_INST_D == 0 || DD_INST_D == 6
-hipError_t launch_hmm_d6(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
+    if (fold && !gbt && K == 1) return launch_one<1, 6, false, true>(A, g, waves, lds, st);
+    if (fold && !gbt && K == 2) return launch_one<2, 6, false, true>(A, g, waves, lds, st);
     return gbt ? launch_k<6, true>(K, A, g, waves, lds, st) : launch_k<6, false>(K, A, g, waves, lds, st);
 }
 #endif
@@ -1068,10 +1144,10 @@ hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int wave
 #endif
 
 #ifdef DD_INST_COMMON
-hipError_t launch_hmm(int K, int Dt, bool gbt, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
     switch (Dt) {
-    case 6: return launch_hmm_d6(K, gbt, A, dim3(grid), waves, lds, st);
+    case 6: return launch_hmm_d6(K, gbt, fold, A, dim3(grid), waves, lds, st);
     case 11: return launch_hmm_d11(K, gbt, A, dim3(grid), waves, lds, st);
     case 12: return launch_hmm_d12(K, gbt, A, dim3(grid), waves, lds, st);
     default: return hipErrorInvalidValue;

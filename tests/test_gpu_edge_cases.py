@@ -435,3 +435,31 @@ def test_multi_device_entry_equals_single_call(lib, faster):
     bad = np.asarray([0, 99], np.int32)
     assert fnm(C.byref(p), C.byref(b), C.byref(resm), bad.ctypes.data_as(capi.c_i32p), 2) == capi.DD_ERR_NO_DEVICE
     assert "block 1" in capi.last_error()
+
+
+@pytest.mark.parametrize("hs", [30, 59, 60, 61, 100, 118, 120, 121, 123, 124])
+def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
+    """Round 3: for K <= 2 at D = 6 the right->middle pass carries the LO / RO end states in the generic candidate code
+    (hmm_kernel.hip, FOLD) when the haplotypes leave three idle positions (64 K >= Hs + 5); haplotype lengths either side of that
+    bound, both parities of RO's slot, reads hanging over both ends (LO / RO stay runs, entering and leaving the haplotype): the
+    FOLD build, the build with the one-lane blocks (DD_NO_FOLD) and the oracle agree bit for bit."""
+    hap = rnd(hs)
+    alt = hap[:hs // 2] + hap[hs // 2 + 1:]                       # one base deleted: the longer haplotype decides the build
+    reads = reads_from(hap, 40, 36 if hs < 62 else 80, junk=0.15)
+    reads += [ReadRec(rnd(12) + hap[:30], [0.999] * 42, 0.9999, 1000 - 12), ReadRec(hap[-30:] + rnd(15), [0.99] * 45, 0.999, 1000 + hs - 30),
+              ReadRec(rnd(40), [0.9] * 40, 0.5, 1000 + hs + 500)]
+    ws = [Window(1000, [hap, alt], reads)]
+    pb = pack(ws)
+    p = capi.params_cli_defaults()
+    folded = run_host_api(lib, p, pb)
+    name_folded = lib.dd_kernel_name().decode()
+    monkeypatch.setenv("DD_NO_FOLD", "1")
+    plain = run_host_api(lib, p, pb)
+    name_plain = lib.dd_kernel_name().decode()
+    monkeypatch.delenv("DD_NO_FOLD")
+    want = _oracle.batch(p, pb, nthreads=8)
+    assert_same(folded, want, pb)
+    assert_same(plain, want, pb)
+    K = (max(len(hap), len(alt)) + 2 + 63) // 64
+    fits = 64 * K >= max(len(hap), len(alt)) + 5
+    assert name_plain.endswith("false>") and name_folded.endswith("true>" if fits else "false>"), (name_folded, name_plain)
