@@ -100,9 +100,12 @@ def algorithmic_bytes_per_pair(L, Hs, R):
 def measured_traffic(n_pairs, kernel_sub="dd_hmm_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, profiles/r*/..._pmc.json) — only when the profiled launch had
-    exactly this many pairs; otherwise None.  bench.py itself cannot collect PMC counters."""
+    exactly this many pairs AND the file was measured on the kernel sources of this tree (`source_id`, a hash of
+    csrc/hmm_kernel.{h,hip}; a file of another build is reported as stale, never quoted); otherwise None.
+    bench.py itself cannot collect PMC counters."""
     import glob
-    best = None
+    best, stale = None, None
+    here = capi.kernel_source_id(kernel_sub)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc.json"))):
         try:
             d = json.load(open(f))
@@ -112,8 +115,12 @@ def measured_traffic(n_pairs, kernel_sub="dd_hmm_kernel"):
             continue
         for cfg in d.values():
             if isinstance(cfg, dict) and cfg.get("pairs_per_launch") == n_pairs and "hbm_bytes_raw" in cfg:
-                best = dict(bytes=cfg["hbm_bytes_raw"], source=os.path.relpath(f, ROOT))
-    return best
+                if d.get("source_id") == here:
+                    best = dict(bytes=cfg["hbm_bytes_raw"], source=os.path.relpath(f, ROOT))
+                else:
+                    stale = dict(bytes=None, source="stale: %s was measured on another build of the kernel (source_id %s, this tree %s)"
+                                                    % (os.path.relpath(f, ROOT), d.get("source_id"), here))
+    return best or stale
 
 
 def cpu_baseline(pb, params, seconds_target=15.0, faster=False):

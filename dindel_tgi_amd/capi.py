@@ -198,3 +198,14 @@ def hpos_reference_codes(hpos):
     h = np.asarray(hpos).copy()
     h[h < DD_HPOS_INS_KEY0] = DD_HPOS_INS
     return h
+
+
+def kernel_source_id(kernel="dd_hmm_kernel"):
+    """Identity of the sources a kernel is built from (12 hex digits of a SHA-1 over the files): profiles/*_pmc.json records it, and
+    bench.py quotes a file's HBM-traffic counters only for the kernel they were measured on."""
+    import hashlib
+    files = ["hmm_kernel.h", "faster_kernel.hip" if "faster" in kernel else "hmm_kernel.hip"]
+    h = hashlib.sha1()
+    for f in files:
+        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    return h.hexdigest()[:12]

@@ -399,8 +399,11 @@ int main(int argc, char **argv)
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                     Batch &B = *b;
                     std::atomic<size_t> next(0);
+                    // a helper thread must not let anything escape (std::terminate): whatever diploidGLF, the CIGAR step or the BAM writer
+                    // throws beside the reference's strings ends the run through fail(), and the helpers stop taking windows
                     auto work = [&]() {
                         const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
+                        try {
                         for (;;) {
                             const size_t i = next.fetch_add(1);
                             if (i >= B.tasks.size()) break;
@@ -432,6 +435,8 @@ int main(int argc, char **argv)
                             if (T.skipped) local.output(skippedWindowLine(local, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
                             T.lines = os.str();
                         }
+                        } catch (std::exception &e) { next.store(B.tasks.size()); fail(std::string("reduce: ") + e.what()); }
+                        catch (...) { next.store(B.tasks.size()); fail("reduce: unknown exception"); }
                         const double dt = seconds_since(w0);
                         std::lock_guard<std::mutex> lk(fatal_m);
                         t_reduce_work += dt;

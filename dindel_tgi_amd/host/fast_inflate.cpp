@@ -46,8 +46,8 @@ bool buildTable(const uint8_t *lens, int n, int primaryBits, Entry *table, int t
     }
     int left = 1;
     for (int l = 1; l <= kMaxCodeLen; l++) { left = (left << 1) - count[l]; if (left < 0) return false; }
-    if (left > 0) {                                 // incomplete: only the one-code distance tree is allowed (3.2.7)
-        if (kind != DISTANCE || n - count[0] != 1) return false;
+    if (left > 0) {                                 // incomplete: only the distance tree of ONE code of ONE bit is allowed (3.2.7; zlib:
+        if (kind != DISTANCE || n - count[0] != 1 || count[1] != 1) return false;     // `left > 0 && max != 1` is an error) — anything else goes to zlib
     }
     unsigned next[kMaxCodeLen + 2];
     unsigned code = 0;
@@ -320,9 +320,14 @@ uint32_t crcFold(uint32_t c, const uint8_t *buf, size_t len)          // len >= 
     x1 = _mm_xor_si128(x1, x2);
     return uint32_t(_mm_extract_epi32(x1, 1));
 }
-const bool g_hasClmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+// decided on first use (a static initialiser may run before the CPU model has been probed: __builtin_cpu_init first, GCC manual 6.60.x)
+bool hasClmul()
+{
+    static const bool yes = (__builtin_cpu_init(), __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"));
+    return yes;
+}
 #else
-const bool g_hasClmul = false;
+bool hasClmul() { return false; }
 uint32_t crcFold(uint32_t c, const uint8_t *, size_t) { return c; }
 #endif
 
@@ -332,7 +337,7 @@ uint32_t fastCrc32(uint32_t crc, const uint8_t *buf, size_t len)
 {
     if (!g_crcTableReady) makeCrcTable();
     uint32_t c = ~crc;
-    if (g_hasClmul && len >= 64) {
+    if (hasClmul() && len >= 64) {
         const size_t body = len & ~size_t(15);
         c = crcFold(c, buf, body);
         buf += body; len -= body;

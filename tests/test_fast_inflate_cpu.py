@@ -103,3 +103,57 @@ def test_crc32_equals_zlib():
     a, b = blob[:12345], blob[12345:40000]
     assert lib.ddh_fast_crc32(lib.ddh_fast_crc32(0, a, len(a)), b, len(b)) == zlib.crc32(a + b)
     assert lib.ddh_fast_crc32(0, bytes(1000), 1000) == zlib.crc32(bytes(1000)) and lib.ddh_fast_crc32(0, b"\xff" * 777, 777) == zlib.crc32(b"\xff" * 777)
+
+
+class _Bits:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def bits(self, v, n):                       # a field, least significant bit first (RFC 1951 3.1.1)
+        self.acc |= v << self.n
+        self.n += n
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def huff(self, code, n):                    # a Huffman code, most significant bit first
+        for i in range(n - 1, -1, -1):
+            self.bits((code >> i) & 1, 1)
+
+    def done(self):
+        if self.n:
+            self.bits(0, 8 - self.n)
+        return bytes(self.out)
+
+
+def _one_code_distance_stream(dist_code_len):
+    """A dynamic block whose distance tree has ONE code, of `dist_code_len` bits: 'A', a match (length 3, distance 1), end of block."""
+    w = _Bits()
+    w.bits(1, 1); w.bits(2, 2)                                  # BFINAL, BTYPE = dynamic
+    w.bits(1, 5); w.bits(0, 5); w.bits(14, 4)                   # HLIT = 258 codes, HDIST = 1 code, HCLEN = 18 lengths
+    cl = {18: 1, 2: 2, 1: 2}                                    # code-length alphabet: 18 -> '0', 1 -> '10', 2 -> '11'
+    for sym in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1):
+        w.bits(cl.get(sym, 0), 3)
+    zeros = lambda n: (w.huff(0, 1), w.bits(n - 11, 7))
+    one = lambda: w.huff(0b10, 2)
+    two = lambda: w.huff(0b11, 2)
+    zeros(65); one()                                            # literal 65 'A': 1 bit
+    zeros(138); zeros(52)                                       # literals 66..255 unused
+    two(); two()                                                # 256 (end of block) and 257 (length 3): 2 bits each
+    (one if dist_code_len == 1 else two)()                      # the single distance code
+    w.huff(0, 1)                                                # 'A'
+    w.huff(0b11, 2); w.huff(0, dist_code_len)                   # length 3, distance code 0 (distance 1)
+    w.huff(0b10, 2)                                             # end of block
+    return w.done()
+
+
+def test_one_code_distance_tree_only_with_a_one_bit_code(check):
+    """RFC 1951 3.2.7 / zlib's inftrees (`left > 0 && max != 1` is an error): an incomplete distance tree is legal only as ONE code of ONE
+    bit.  The own decoder takes exactly what zlib takes; the two-bit variant is declined (and would go to zlib, which rejects the block)."""
+    ok, bad = _one_code_distance_stream(1), _one_code_distance_stream(2)
+    assert zlib.decompress(ok, -15) == b"AAAA"
+    with pytest.raises(zlib.error):
+        zlib.decompress(bad, -15)
+    assert check(ok, b"AAAA") == 1
+    assert check(bad, b"AAAA") == 0

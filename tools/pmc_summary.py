@@ -43,6 +43,13 @@ def main():
             cfg["lds_bank_conflict_frac"] = cfg["SQ_LDS_BANK_CONFLICT"] / cfg["SQ_LDS_IDX_ACTIVE"]
         cfg["kernel_ms_unprofiled"] = b["roofline"]["kernel_ms"]
     out["config"] = cfg
+    try:                                          # which sources the counters belong to (bench.py quotes them only for that kernel)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from dindel_tgi_amd import capi
+        out["source_id"] = capi.kernel_source_id(pat)
+    except Exception as e:                        # noqa: BLE001
+        out["source_id"] = "unknown: %r" % (e,)
     print(json.dumps(out, indent=1))
 
 
