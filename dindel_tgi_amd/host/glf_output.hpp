@@ -96,6 +96,22 @@ public:
         numLines++;
         *out << line.toString() << std::endl;
     }
+    // a line already in its final text (GlfText below), without the trailing newline
+    void outputText(const std::string &text)
+    {
+        numLines++;
+        out->write(text.data(), std::streamsize(text.size()));
+        out->put('\n');
+        out->flush();
+    }
+    // true when the columns are exactly makeGLFOutputData's, in that order: the window loop then writes its two kinds of lines
+    // through GlfText (one pass over the 32 cells) instead of through a Line (a label lookup and a string per cell)
+    bool hasGLFColumns() const { return glfColumns; }
+    void noteColumns(const char *const *expected, size_t n)
+    {
+        glfColumns = labels.size() == n;
+        for (size_t i = 0; glfColumns && i < n; i++) glfColumns = labels[i] == expected[i];
+    }
     int lines() const { return numLines; }
     std::ostream *out;
 
@@ -103,6 +119,7 @@ private:
     std::map<std::string, int> labelToColumn;
     std::vector<std::string> labels;
     int numLines;
+    bool glfColumns = false;
 };
 
 // DetInDelParameters::makeGLFOutputData — reference DInDel.hpp:262-276
@@ -118,6 +135,10 @@ inline OutputData makeGLFOutputData(std::ostream &out)
     oData("var_coverage_forward")("var_coverage_reverse");
     oData("nBQT")("nmmBQT")("mLogBQ")("nMMLeft")("nMMRight");
     oData("glf");
+    static const char *const columns[32] = {"msg", "index", "analysis_type", "tid", "lpos", "rpos", "center_position", "realigned_position", "was_candidate_in_window",
+        "ref_all", "nref_all", "num_reads", "post_prob_variant", "qual", "est_freq", "logZ", "hapfreqs", "indidx", "msq", "numOffAll", "num_indel", "num_cover_forward",
+        "num_cover_reverse", "num_unmapped_realigned", "var_coverage_forward", "var_coverage_reverse", "nBQT", "nmmBQT", "mLogBQ", "nMMLeft", "nMMRight", "glf"};
+    oData.noteColumns(columns, 32);
     return oData;
 }
 
@@ -229,6 +250,89 @@ inline OutputData::Line dipPositionLine(const OutputData &glfData, const DipPosi
     line.set("glf", c.glf);
     line.set("num_unmapped_realigned", c.numUnmappedRealigned);
     return line;
+}
+
+// The same two lines as text, cell after cell in the column order of makeGLFOutputData (OutputData::hasGLFColumns()): what
+// dipMapLine(...).toString() / dipPositionLine(...).toString() give — an unset cell is "NA", integers are decimal digits, doubles
+// "%.6g" — without a Line object (32 strings and ~25 label lookups per line; eight lines per window add up to a fifth of the
+// reduce stage).  tests/test_glf_vcf_cpu.py holds both forms against each other.
+// "%.6g" of a double — what `ostream << x` prints with the default format — without going through printf for the common case.
+// The six significant digits are taken from |x| scaled by an exact power of ten (10^k is exact in fp64 for k <= 22, and a single
+// multiplication or division by it is off by at most half an ulp); they are trusted only when the scaled value lies further from a
+// rounding boundary (.5) than that error could ever reach, otherwise — and for anything outside 1e-5 <= |x| < 1e15, zero, inf, nan —
+// snprintf decides.  tests/test_glf_vcf_cpu.py compares it with snprintf on random, boundary and tie values.
+inline int formatG6(double x, char *out)
+{
+    static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const double a = x < 0 ? -x : x;
+    if (!(a >= 1e-5 && a < 1e15)) return snprintf(out, 32, "%.6g", x);
+    int e = 0;                                             // decimal exponent of the leading digit: 10^e <= a < 10^(e+1)
+    if (a >= 1.0) { while (e < 22 && a >= p10[e + 1]) e++; }
+    else { e = -1; while (a * p10[-e] < 1.0) e--; }        // a * 10^-e in [1, 10) (the product may round across: checked below)
+    const int shift = 5 - e;                               // scale to six digits in front of the point
+    const double y = shift >= 0 ? a * p10[shift] : a / p10[-shift];
+    double r = double((long long)(y + 0.5));
+    const double frac = y - (r - 0.5);                     // distance above the lower boundary r - 0.5, in [0, 1)
+    if (!(y >= 99999.5 && y < 999999.5) || frac < 1e-4 || frac > 1.0 - 1e-4 || r >= 1e6 || r < 1e5) return snprintf(out, 32, "%.6g", x);
+    long long digits = (long long)r;                       // 100000 .. 999999
+    char d[6];
+    for (int i = 5; i >= 0; i--) { d[i] = char('0' + digits % 10); digits /= 10; }
+    int nd = 6;
+    while (nd > 1 && d[nd - 1] == '0') nd--;               // %g strips trailing zeros
+    char *o = out;
+    if (x < 0) *o++ = '-';
+    if (e < -4 || e >= 6) {                                // d.ddddde+XX
+        *o++ = d[0];
+        if (nd > 1) { *o++ = '.'; for (int i = 1; i < nd; i++) *o++ = d[i]; }
+        *o++ = 'e'; *o++ = e < 0 ? '-' : '+';
+        const int ae = e < 0 ? -e : e;
+        *o++ = char('0' + ae / 10); *o++ = char('0' + ae % 10);
+    } else if (e >= 0) {                                   // e + 1 digits, a point, the rest
+        for (int i = 0; i <= e; i++) *o++ = i < nd ? d[i] : '0';
+        if (nd > e + 1) { *o++ = '.'; for (int i = e + 1; i < nd; i++) *o++ = d[i]; }
+    } else {                                               // 0.000ddd
+        *o++ = '0'; *o++ = '.';
+        for (int i = -1; i > e; i--) *o++ = '0';
+        for (int i = 0; i < nd; i++) *o++ = d[i];
+    }
+    *o = 0;
+    return int(o - out);
+}
+
+class GlfText {
+public:
+    explicit GlfText(std::string &buffer) : s(buffer), first(true) { s.clear(); }
+    GlfText &na() { sep(); s += "NA"; return *this; }
+    GlfText &cell(const std::string &x) { sep(); s += x; return *this; }
+    GlfText &cell(const char *x) { sep(); s += x; return *this; }
+    GlfText &cell(double x) { char b[64]; const int n = formatG6(x, b); sep(); s.append(b, size_t(n)); return *this; }
+    GlfText &cell(long long x) { char b[32]; const int n = snprintf(b, sizeof(b), "%lld", x); sep(); s.append(b, size_t(n)); return *this; }
+    GlfText &cell(int x) { return cell((long long)x); }
+    GlfText &cell(unsigned x) { return cell((long long)x); }
+    GlfText &cell(unsigned long x) { char b[32]; const int n = snprintf(b, sizeof(b), "%lu", x); sep(); s.append(b, size_t(n)); return *this; }
+private:
+    void sep() { if (!first) s += ' '; first = false; }
+    std::string &s; bool first;
+};
+
+inline void dipMapText(std::string &out, const DipMapCall &c)
+{
+    char genoqual[64];
+    formatG6(c.genoqual, genoqual);
+    GlfText t(out);
+    t.cell("ok").cell(c.index).cell("dip.map").cell(c.tid).cell(c.leftPos).cell(c.rightPos).cell(c.candPos).cell(c.realignedPos).cell(c.was_candidate);
+    t.na().cell(c.nref_all).cell((unsigned long)c.num_reads).na().cell(c.qual).na().na().na().cell(0).cell(c.msq).na().na().cell(c.numf).cell(c.numr);
+    t.cell(c.numUnmappedRealigned).cell(c.vc_f).cell(c.vc_r).na().na().na().na().na();
+    t.cell(c.genotype + ":" + genoqual);
+}
+
+inline void dipPositionText(std::string &out, const DipPositionRow &c)
+{
+    GlfText t(out);
+    t.cell("ok").cell(c.index).cell(c.program).cell(c.tid).cell(c.leftPos).cell(c.rightPos).cell(c.candPos).cell(c.realignedPos).cell(c.has_variants_in_window);
+    t.na().cell(c.nref_all).cell((unsigned long)c.num_reads).na().na().na().cell(c.logZ).na().cell(0).cell(c.msq).cell(c.numOffAll).cell(c.num_indel).cell(c.nf).cell(c.nr);
+    t.cell(c.numUnmappedRealigned).cell(c.var_coverage_forward).cell(c.var_coverage_reverse).cell(c.nBQT).cell(c.nmmBQT).cell(c.mLogBQ / double(c.nBQT));
+    t.cell(c.nMMLeft).cell(c.nMMRight).cell(c.glf);
 }
 
 } // namespace dindel

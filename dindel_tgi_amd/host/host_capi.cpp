@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <sstream>
 #include <string>
 #include "compute_likelihoods.hpp"
@@ -493,6 +494,40 @@ int ddh_bench_batch(int W, int H, int R, int L, int HL, unsigned long long seed,
 extern "C" {
 
 // how the table prints a double: default ostream formatting (6 significant digits), as OutputData::Line::set does
+// formatG6 (glf_output.hpp) against snprintf("%.6g") on `n` values: log-uniform magnitudes over 1e-7 .. 1e17 with both signs, values
+// sitting on and one ulp either side of six-digit rounding boundaries (d.ddddd5 x 10^k), powers of ten, and small integers.  Returns
+// the number of values whose text differs (0 is the test) and writes the first difference to `out`.
+int ddh_format_g6_check(unsigned long long seed, int n, char *out, int cap)
+{
+    unsigned long long st = seed ? seed : 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    int bad = 0;
+    std::string firstBad;
+    auto one = [&](double x) {
+        char a[64], b[64];
+        formatG6(x, a);
+        snprintf(b, sizeof(b), "%.6g", x);
+        if (strcmp(a, b) != 0) { if (!bad) { char m[200]; snprintf(m, sizeof(m), "%.17g: %s vs %s", x, a, b); firstBad = m; } bad++; }
+    };
+    for (int i = 0; i < n; i++) {
+        const double u = double(rnd() >> 11) / 9007199254740992.0, v = double(rnd() >> 11) / 9007199254740992.0;
+        const double mag = pow(10.0, -7.0 + 24.0 * u) * (1.0 + v);
+        one(mag); one(-mag);
+        // a six-digit boundary: (d + 0.5) x 10^k with d a 6-digit integer, and its neighbours
+        const long long d = 100000 + (long long)(rnd() % 900000);
+        const int k = int(rnd() % 22) - 11;
+        const double tie = (double(d) + 0.5) * pow(10.0, double(k));
+        one(tie); one(nextafter(tie, 0.0)); one(nextafter(tie, 1e300)); one(-tie);
+        one(double(d) * pow(10.0, double(k)));
+        one(double((long long)(rnd() % 2000000)) - 1000000.0);
+    }
+    const double odd[] = {0.0, -0.0, 1.0, 10.0, 100000.0, 999999.0, 999999.5, 999999.4999999999, 1e6, 1e-4, 9.9999949999e-5, 9.9999950001e-5, 1e-5, 1e15, 123456.5, 0.1, 1.0 / 3.0,
+                          HUGE_VAL, -HUGE_VAL, NAN, 5e-324, 1.7976931348623157e308};
+    for (size_t i = 0; i < sizeof(odd) / sizeof(odd[0]); i++) one(odd[i]);
+    emit(bad ? firstBad : std::string("ok"), out, cap);
+    return bad;
+}
+
 int ddh_format_double(double x, char *out, int cap)
 {
     std::ostringstream os;
@@ -534,6 +569,11 @@ int ddh_glf_demo(const char *path, const char *thrown, const double *vals)
         d.nref_all = "-AC"; d.num_reads = 173; d.msq = vals[1]; d.numOffAll = 4; d.num_indel = 21; d.nf = 11; d.nr = 9;
         d.var_coverage_forward = "12"; d.var_coverage_reverse = "10"; d.glf = "0/0:-310.5,0/1:-250.25,1/1:-400"; d.numUnmappedRealigned = 2;
         glf.output(dipPositionLine(glf, d));
+        // the same two lines through the text writers the window loop uses (GlfText): lines 5 and 6 of the file
+        if (!glf.hasGLFColumns()) return -2;
+        std::string text;
+        dipMapText(text, c); glf.outputText(text);
+        dipPositionText(text, d); glf.outputText(text);
         return glf.lines();
     } catch (std::string &e) {
         return -1;

@@ -47,9 +47,15 @@ def test_glf_table_header_rows_and_na_defaults(tmp_path):
     path = str(tmp_path / "demo.glf.txt")
     vals = (C.c_double * 5)(37.123456, 45.6789012, 12.987654321, -1234.56789, -4500.0)
     lib.ddh_glf_demo.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]
-    assert lib.ddh_glf_demo(path.encode(), b"hapSize error.", vals) == 3
+    assert lib.ddh_glf_demo(path.encode(), b"hapSize error.", vals) == 5
     lines = open(path).read().split("\n")
-    assert lines[0].split(" ") == GLF_COLUMNS and lines[4] == ""                 # DInDel.hpp:262-276, one endl per line
+    assert lines[0].split(" ") == GLF_COLUMNS and lines[6] == "" and len(lines) == 7  # DInDel.hpp:262-276, one endl per line
+    assert lines[4] == lines[2] and lines[5] == lines[3]                           # the window loop's text writers (GlfText) = the Line objects
+    for bad in ((float("nan"), 1.0, 2.0, 3.0, 0.0), (1e300, -1e-300, 5e-324, float("inf"), float("-inf"))):    # what "%.6g" makes of odd values
+        p2 = str(tmp_path / "odd.glf.txt")
+        assert lib.ddh_glf_demo(p2.encode(), b"x", (C.c_double * 5)(*bad)) == 5
+        odd = open(p2).read().split("\n")
+        assert odd[4] == odd[2] and odd[5] == odd[3]
     rows = [dict(zip(GLF_COLUMNS, l.split(" "))) for l in lines[1:4]]
     # skipped window: only msg / index / tid / lpos / rpos are set, blanks of the thrown string become '_' (DInDel.cpp:1366-1395)
     assert rows[0]["msg"] == "error_hapSize_error." and (rows[0]["index"], rows[0]["tid"], rows[0]["lpos"], rows[0]["rpos"]) == ("7", "20", "1000123", "1000243")
@@ -63,6 +69,16 @@ def test_glf_table_header_rows_and_na_defaults(tmp_path):
     # per-position "dip" line (DInDel.cpp:3616-3650): mLogBQ is written divided by nBQT
     assert rows[2]["analysis_type"] == "dip" and rows[2]["logZ"] == "-1234.57" and rows[2]["mLogBQ"] == "-0.3" and rows[2]["nBQT"] == "15000"
     assert rows[2]["glf"] == "0/0:-310.5,0/1:-250.25,1/1:-400" and rows[2]["qual"] == "NA" and rows[2]["numOffAll"] == "4"
+
+
+def test_fast_six_digit_formatter_equals_printf():
+    """GlfText formats doubles with its own "%.6g" (scaled by an exact power of ten, trusted only away from rounding boundaries, snprintf
+    otherwise): two million values incl. exact ties and their neighbours give printf's text."""
+    lib = hostlib.load()
+    lib.ddh_format_g6_check.argtypes = [C.c_ulonglong, C.c_int, C.c_char_p, C.c_int]
+    out = C.create_string_buffer(256)
+    for seed in (1, 2026):
+        assert lib.ddh_format_g6_check(seed, 150000, out, 256) == 0, out.value.decode()
 
 
 # ---------------- glf -> VCF ----------------
