@@ -174,7 +174,12 @@ def window_loop_leg(faster, windows=40000):
                 row = json.loads(line)
                 wall = float(row["driver"].split("wall=")[1].split()[0])
                 if best is None or wall < best["seconds"]:
-                    best = {"seconds": wall, "windows_per_s": windows / wall, "stages": row["driver"], "lines_written": row["dip_map_lines"] * 8 + 1}
+                    f = lambda key: float(row["driver"].split(key + "=")[1].split()[0].rstrip(")"))
+                    best = {"seconds": wall, "windows_per_s": windows / wall, "stages": row["driver"], "lines_written": row["dip_map_lines"] * 8 + 1,
+                            # the rate once the pipeline is full (from the batch that completed the first fifth of the windows to the last one)
+                            "steady_windows_per_s": f("steady_windows_per_s") if "steady_windows_per_s=" in row["driver"] else None,
+                            # host CPU per window, summed over the threads of each stage: read selection, packing, diploidGLF + lines
+                            "cpu_ms_per_window": {"prepare": 1e3 * f("prepare") / windows, "pack": 1e3 * f("pack") / windows, "reduce": 1e3 * f("work") / windows}}
         if best is None:
             return {"error": (r.stderr or r.stdout)[-400:]}
         best["what"] = ("%d windows x 8 haplotypes x ~200 reads of 100 bp from a coordinate-sorted BAM through getReads, the likelihood kernels, "

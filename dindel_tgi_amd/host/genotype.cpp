@@ -1,7 +1,7 @@
 // genotype.cpp — see genotype.hpp.
 #include "genotype.hpp"
 #include <cmath>
-#include <set>
+#include <cstdint>
 #include <string>
 
 namespace dindel {
@@ -53,48 +53,55 @@ PairPosteriorResult diploidPairPosteriors(int nh, const std::vector<double> &pai
     return R;
 }
 
+// DetInDel::filterHaplotypes on eager records (the view-based form the window loop uses is in diploid_glf.cpp).  Reads are numbered, so
+// the reference's sets of read indices are bit sets here; a variant's coverage over the haplotypes that are kept is the OR of its rows.
 void filterHaplotypes(const std::vector<Haplotype> &haps, const std::vector<Read> &reads,
                       const std::vector<std::vector<MLAlignment> > &liks, std::vector<int> &filtered,
                       std::map<VariantKey, VariantCoverage> &varCoverage, bool doFilter)
 {
-    const int numHaps = int(haps.size());
-    filtered = std::vector<int>(haps.size(), 0);
-    varCoverage.clear();
-    std::map<VariantKey, std::vector<std::set<int> > > hVarCoverage;
-    for (int h = 0; h < numHaps; h++) {
-        std::set<int> selReads;                                              // :1951-1955
-        for (size_t r = 0; r < reads.size(); r++)
-            if (!liks[h][r].offHapHMQ && liks[h][r].numIndels == 0) selReads.insert(int(r));
-        bool allCovered = true;
-        for (std::map<int, AlignedVariant>::const_iterator it = haps[h].indels.begin(); it != haps[h].indels.end(); ++it) {
-            const AlignedVariant &av = it->second;
-            const VariantKey pav(it->first, av.getString());
-            if (hVarCoverage.find(pav) == hVarCoverage.end()) hVarCoverage[pav] = std::vector<std::set<int> >(haps.size() * 2);
-            if (av.getType() == AlignedVariant::INS || av.getType() == AlignedVariant::DEL) {
-                bool covered = false;
-                for (std::set<int>::const_iterator rt = selReads.begin(); rt != selReads.end(); ++rt) {
-                    const int r = *rt;
-                    int strand = 0;                                          // :1982-1987
-                    if (reads[r].isUnmapped()) { if (!reads[r].mateIsReverse()) strand = 1; }
-                    else { if (reads[r].isReverse()) strand = 1; }
-                    std::map<int, bool>::const_iterator f = liks[h][r].hapIndelFilterCovered.find(it->first);
-                    if (f != liks[h][r].hapIndelFilterCovered.end() && f->second) {
-                        hVarCoverage[pav][h + strand * numHaps].insert(r);
-                        covered = true;
-                    }
-                }
-                if (!covered) { allCovered = false; break; }                 // :2060-2063
-            }
-        }
-        if (doFilter && !allCovered) filtered[h] = 1;                        // :2068-2073
+    const size_t nh = haps.size(), nr = reads.size(), words = (nr + 63) / 64;
+    typedef std::vector<uint64_t> Bits;
+    Bits reverse(words, 0);                                                  // the strand a read counts for (:1982-1987)
+    for (size_t r = 0; r < nr; r++) {
+        const bool rev = reads[r].isUnmapped() ? !reads[r].mateIsReverse() : reads[r].isReverse();
+        if (rev) reverse[r >> 6] |= uint64_t(1) << (r & 63);
     }
-    for (std::map<VariantKey, std::vector<std::set<int> > >::const_iterator it = hVarCoverage.begin(); it != hVarCoverage.end(); ++it) {
-        std::set<int> rf, rr;                                                // :2088-2097
-        for (int h = 0; h < numHaps; h++) if (filtered[h] != 1) {
-            rf.insert(it->second[h].begin(), it->second[h].end());
-            rr.insert(it->second[h + numHaps].begin(), it->second[h + numHaps].end());
+    struct Row { VariantKey key; size_t hap; Bits covering; };
+    std::vector<Row> rows;                                                   // one per (haplotype, variant) the walk got to
+    filtered.assign(nh, 0);
+    for (size_t h = 0; h < nh; h++) {
+        bool everyIndelCovered = true;
+        for (std::map<int, AlignedVariant>::const_iterator it = haps[h].indels.begin(); it != haps[h].indels.end() && everyIndelCovered; ++it) {
+            Row row;
+            row.key = VariantKey(it->first, it->second.getString());
+            row.hap = h;
+            row.covering.assign(words, 0);
+            if (it->second.isIndel()) {
+                bool any = false;
+                for (size_t r = 0; r < nr; r++) {
+                    const MLAlignment &ml = liks[h][r];
+                    if (ml.offHapHMQ || ml.numIndels != 0) continue;             // the reads selected for this haplotype (:1951-1955)
+                    const std::map<int, bool>::const_iterator f = ml.hapIndelFilterCovered.find(it->first);
+                    if (f != ml.hapIndelFilterCovered.end() && f->second) { row.covering[r >> 6] |= uint64_t(1) << (r & 63); any = true; }
+                }
+                if (!any) everyIndelCovered = false;                             // :2060-2063: the walk over this haplotype ends here
+            }
+            rows.push_back(row);                                                 // (a variant without covering reads still gets its entry)
         }
-        varCoverage[it->first] = VariantCoverage(int(rf.size()), int(rr.size()));
+        if (doFilter && !everyIndelCovered) filtered[h] = 1;                     // :2068-2073
+    }
+    varCoverage.clear();
+    std::map<VariantKey, std::pair<Bits, Bits> > united;                         // forward, reverse reads over the haplotypes kept (:2088-2097)
+    for (size_t k = 0; k < rows.size(); k++) {
+        std::pair<Bits, Bits> &u = united[rows[k].key];
+        if (u.first.empty()) { u.first.assign(words, 0); u.second.assign(words, 0); }
+        if (filtered[rows[k].hap] == 1) continue;
+        for (size_t w = 0; w < words; w++) { u.first[w] |= rows[k].covering[w] & ~reverse[w]; u.second[w] |= rows[k].covering[w] & reverse[w]; }
+    }
+    for (std::map<VariantKey, std::pair<Bits, Bits> >::const_iterator it = united.begin(); it != united.end(); ++it) {
+        int nf = 0, nrv = 0;
+        for (size_t w = 0; w < words; w++) { nf += __builtin_popcountll(it->second.first[w]); nrv += __builtin_popcountll(it->second.second[w]); }
+        varCoverage[it->first] = VariantCoverage(nf, nrv);
     }
 }
 

@@ -14,7 +14,8 @@
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define ITER 2000
 
-template <int OP>
+// LANES < 64: the timed loop runs under an EXEC mask of the wave's first LANES lanes (what the HMM kernel's one-lane LO / RO blocks do)
+template <int OP, int LANES = 64>
 __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long long *cyc, double seed)
 {
     double a[8], b[8];
@@ -23,6 +24,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
     for (int i = 0; i < 8; i++) { a[i] = seed * (i + 1) + threadIdx.x * 1e-9; b[i] = -seed * (i + 2); u[i] = threadIdx.x + i; f[i] = float(i) + float(seed); }
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (LANES == 64 || (threadIdx.x & 63) < LANES)
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
 static double *g_out = nullptr;
 static unsigned long long *g_cyc = nullptr;
 
-template <int OP> static void run(const char *name, int instr_per_x)
+template <int OP, int LANES = 64> static void run(const char *name, int instr_per_x)
 {
     for (int w = 1; w <= 4; w++) {   // (round 2's w = 4 fault: OP 9 / OP 13 wrote u[i] through an input-only operand, so the register that also held
                                      //  threadIdx.x drifted and the final store left the buffer; every written register is an output operand now)
@@ -108,10 +110,10 @@ template <int OP> static void run(const char *name, int instr_per_x)
         }
         double *out = g_out;
         unsigned long long *cyc = g_cyc;
-        hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
+        hipLaunchKernelGGL((rate_kernel<OP, LANES>), dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
         CHECK(hipGetLastError());
         CHECK(hipDeviceSynchronize());
-        hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
+        hipLaunchKernelGGL((rate_kernel<OP, LANES>), dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.25);
         CHECK(hipGetLastError());
         CHECK(hipDeviceSynchronize());
         std::vector<unsigned long long> h(blocks * (threads / 64));
@@ -143,5 +145,11 @@ int main()
     run<11>("v_min_u32", 1);
     run<12>("v_pk_add_f32", 1);
     run<13>("cmp_ge_f64+cndmask (2)", 2);
+    // sparse EXEC masks: does a wave64 instruction with few enabled lanes cost less?
+    run<0, 32>("v_add_f64, lanes 0-31 enabled", 1);
+    run<0, 16>("v_add_f64, lanes 0-15 enabled", 1);
+    run<0, 1>("v_add_f64, lane 0 enabled", 1);
+    run<9, 1>("add+cmp+cndmask (3), lane 0 enabled", 3);
+    run<4, 1>("v_add_u32, lane 0 enabled", 1);
     return 0;
 }
