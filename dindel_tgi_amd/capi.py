@@ -204,8 +204,12 @@ def kernel_source_id(kernel="dd_hmm_kernel"):
     """Identity of the sources a kernel is built from (12 hex digits of a SHA-1 over the files): profiles/*_pmc.json records it, and
     bench.py quotes a file's HBM-traffic counters only for the kernel they were measured on."""
     import hashlib
+    import re
     files = ["hmm_kernel.h", "faster_kernel.hip" if "faster" in kernel else "hmm_kernel.hip"]
     h = hashlib.sha1()
-    for f in files:
-        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    for f in files:                                # the code, not its comments or layout
+        text = open(os.path.join(_HERE, "csrc", f), "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", " ", text).encode())
     return h.hexdigest()[:12]

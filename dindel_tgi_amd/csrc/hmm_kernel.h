@@ -85,7 +85,7 @@ __device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
 }
 
 /* fold: the build whose right->middle pass carries the LO / RO end states in the generic candidate code (K <= 2, D build 6, LDS
- * back-pointers; every haplotype of the launch must leave three idle positions: 64 K >= Hs + 5) */
+ * back-pointers; every haplotype of the launch must leave position 64 K - 1 idle: 64 K >= Hs + 3) */
 hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */

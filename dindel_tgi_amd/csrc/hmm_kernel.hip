@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 1..4 waves (host picks what fits LDS best)
     const int NP = 64 * K;
-    constexpr bool foldLO = FOLD;                   // (host: only for haplotypes with numS <= NP - 3)
+    constexpr bool foldLO = FOLD;                   // (host: only for haplotypes with numS <= NP - 1)
     const int Dr = P.D;                             // real D (== D unless the generic D=12 build is used)
     const double *T = P.tables;
     const double lLL = T[TC_LLL], lFL = T[TC_LFL], II = T[TC_II], NI = T[TC_NI], NN = T[TC_NN];
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
         if (foldLO) {
             for (int y = 1 + tid; y <= D; y += nthr) {
                 shC[((K - 1) * D + y - 1) * 64 + 63] = y == 2 ? lLL : (y == 3 ? lFL : NEG_INF);
-                if (RO - (RO / K) * K == K - 1) shC[((K - 1) * D + y - 1) * 64 + RO / K] = y == 2 ? 0.0 : NEG_INF;
+                if (RO - (RO / K) * K == K - 1 && numS <= NP - 3) shC[((K - 1) * D + y - 1) * 64 + RO / K] = y == 2 ? 0.0 : NEG_INF;
             }
             __syncthreads();
         }
@@ -350,12 +350,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     //   * RO, when it sits in its lane's last slot (kRO == K-1: its candidates then come from LDS, not from the lane's own
     //     registers), gets {beta[RO], eq} into slot RO+1 and {eq + beta[RO], Nn[RO]} into slot RO+2, c_2 = 0, eInc = 0:
     //       y = 2: (0 + (eq + beta[RO])) + Nn[RO]   -> stays RO;   insertion edge: (eq + beta[numS+RO]) + 0   -> numS+RO   (:1741-1742, :1750)
-    //   Needs the positions NP-3 .. NP-1 idle (numS <= NP-3), so that RO's two slots and LO's position do not collide: the host
-    //   launches the FOLD build only for length classes with 64 K >= Hs + 5 (launch_class, capi.cpp).
-    //   What it buys: the one-lane blocks are 19 of the sweep's 89 fp64 instructions but run with one lane enabled, and a
-    //   sparse EXEC mask costs far less than a full wave instruction — the fold is worth 2-3 % at K <= 2 / D = 6 (245.8 ->
-    //   240.3 ms per 6,000 windows of configs[1]) and nothing or less where the sweep is longer (profiles/r03/fold_ab.txt).
-    const bool foldRO = foldLO && kRO == K - 1;
+    //   LO needs position NP-1 idle (numS <= NP-1: the host launches the FOLD build only for length classes with 64 K >= Hs + 3,
+    //   capi.cpp); RO's two slots must not reach LO's position, so RO is folded only when numS <= NP-3 as well — otherwise its
+    //   one-lane block runs as in the other builds.
+    //   What it buys (profiles/r03/fold_ab.txt): the sweep's loop body goes from 214 to 188 instructions (fp64 89 -> 70), the kernel
+    //   gains 2.3-3.3 % at K <= 2 / D = 6 (245.8 -> 240.3 ms per 6,000 windows of configs[1]) — less than the count suggests, because
+    //   the fold adds two adds, a dozen moves and five masked 8-byte LDS stores in front of the slice exchange — and nothing or less
+    //   where the sweep is longer (D = 11, K >= 3, the LEAN builds: -1 ... -7 %), so only those two builds carry it.
+    const bool foldRO = foldLO && kRO == K - 1 && numS <= NP - 3;
     constexpr int k1 = 1 % K;                       // state 1 lives in lane 1 / K, slot k1
     const int lane1 = 1 / K;
     if (foldLO && lane == 63) eInc[K - 1] = E_1;

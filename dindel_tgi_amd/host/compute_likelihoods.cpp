@@ -220,7 +220,7 @@ struct BatchBlock {
     std::vector<int32_t> win_hap_off, win_read_off, hap_var_off, read_seq_off;
     std::vector<int64_t> pair_off, hpos_off, vc_off;
     RawBuf<double> ll, llOn, llOff, mLogBQ;
-    RawBuf<uint8_t> offHap, offHapHMQ, onHap, vcov, fcov;
+    RawBuf<uint8_t> offHap, offHapHMQ, vcov, fcov;
     RawBuf<int16_t> numIndels, numMismatch, nBQT, nmmBQT, nMMLeft, nMMRight, firstBase, lastBase, hpos;
     RawBuf<int32_t> status;
     BatchBlock() : W(0), faster(false), has_hpos(false) {}
@@ -401,7 +401,15 @@ int WindowLikelihoods::nMMLeft(size_t h, size_t r) const { return blk_->nMMLeft[
 int WindowLikelihoods::nMMRight(size_t h, size_t r) const { return blk_->nMMRight[pair(h, r)]; }
 int WindowLikelihoods::firstBase(size_t h, size_t r) const { return blk_->firstBase[pair(h, r)]; }
 int WindowLikelihoods::lastBase(size_t h, size_t r) const { return blk_->lastBase[pair(h, r)]; }
-int WindowLikelihoods::onHap(size_t r) const { return blk_->onHap[size_t(blk_->win_read_off[w_]) + r]; }
+// onHap[r] = 1 if the read lies on some haplotype under the artificial mapping quality (DInDel.cpp:1720: !liks[hidx][r].offHapHMQ for any hidx).
+// Taken from the offHapHMQ flags here instead of from the device's dd_onhap_kernel: one kernel (and one kernel boundary, ~0.15 ms on
+// this part) less per batch, for a value only the realigned-BAM step reads.
+int WindowLikelihoods::onHap(size_t r) const
+{
+    const size_t nh = numHaps();
+    for (size_t h = 0; h < nh; h++) if (!blk_->offHapHMQ[pair(h, r)]) return 1;
+    return 0;
+}
 
 // slot of the haplotype's variant `key` in the per-pair flag list: hap.indels in map order, then hap.snps (-1: no such variant)
 int WindowLikelihoods::varSlot(size_t h, int key, bool snp) const
@@ -719,7 +727,7 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     Rz.numIndels = B.numIndels.reserve(np); Rz.numMismatch = B.numMismatch.reserve(np); Rz.nBQT = B.nBQT.reserve(np);
     Rz.nmmBQT = B.nmmBQT.reserve(np); Rz.nMMLeft = B.nMMLeft.reserve(np); Rz.nMMRight = B.nMMRight.reserve(np);
     Rz.firstBase = B.firstBase.reserve(np); Rz.lastBase = B.lastBase.reserve(np);
-    Rz.onHap = B.onHap.reserve(size_t(sz.n_reads) + 1);
+    Rz.onHap = NULL;                                    // derived from offHapHMQ on the host (WindowLikelihoods::onHap)
     Rz.var_fcov = B.fcov.reserve(size_t(sz.var_cov_len) + 1); Rz.var_covered = B.vcov.reserve(size_t(sz.var_cov_len) + 1);
     if (B.has_hpos) Rz.hpos = B.hpos.reserve(size_t(sz.hpos_len) + 1);
     dd_params P = to_abi(params);
@@ -731,8 +739,6 @@ void LikelihoodEngine::runBatch(std::vector<WindowJob> &jobs, bool faster)
     if (sz.n_pairs > 0) {
         const int rc = faster ? dd_compute_likelihoods_faster(&P, &Bt, &Rz, device_) : dd_compute_likelihoods(&P, &Bt, &Rz, device_);
         if (rc != DD_SUCCESS) throw std::string(faster ? "dd_compute_likelihoods_faster: " : "dd_compute_likelihoods: ") + dd_last_error();
-    } else {
-        for (int64_t q = 0; q < sz.n_reads; q++) B.onHap[size_t(q)] = 0;
     }
 
     const std::chrono::steady_clock::time_point t_device = std::chrono::steady_clock::now();

@@ -437,11 +437,11 @@ def test_multi_device_entry_equals_single_call(lib, faster):
     assert "block 1" in capi.last_error()
 
 
-@pytest.mark.parametrize("hs", [30, 59, 60, 61, 100, 118, 120, 121, 123, 124])
+@pytest.mark.parametrize("hs", [30, 59, 60, 61, 62, 100, 118, 120, 121, 123, 124, 125, 126])
 def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     """Round 3: for K <= 2 at D = 6 the right->middle pass carries the LO / RO end states in the generic candidate code
-    (hmm_kernel.hip, FOLD) when the haplotypes leave three idle positions (64 K >= Hs + 5); haplotype lengths either side of that
-    bound, both parities of RO's slot, reads hanging over both ends (LO / RO stay runs, entering and leaving the haplotype): the
+    (hmm_kernel.hip, FOLD) when the haplotypes leave the last position idle (64 K >= Hs + 3; RO is folded too when 64 K >= Hs + 5 and it
+    sits in its lane's last slot); haplotype lengths either side of both bounds, both parities of RO's slot, reads hanging over both ends (LO / RO stay runs, entering and leaving the haplotype): the
     FOLD build, the build with the one-lane blocks (DD_NO_FOLD) and the oracle agree bit for bit."""
     hap = rnd(hs)
     alt = hap[:hs // 2] + hap[hs // 2 + 1:]                       # one base deleted: the longer haplotype decides the build
@@ -461,5 +461,5 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     assert_same(folded, want, pb)
     assert_same(plain, want, pb)
     K = (max(len(hap), len(alt)) + 2 + 63) // 64
-    fits = 64 * K >= max(len(hap), len(alt)) + 5
+    fits = 64 * K >= max(len(hap), len(alt)) + 3
     assert name_plain.endswith("false>") and name_folded.endswith("true>" if fits else "false>"), (name_folded, name_plain)
