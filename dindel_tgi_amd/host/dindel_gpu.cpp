@@ -215,10 +215,9 @@ int main(int argc, char **argv)
         rsp.keepRecords = realignedBAM;
         unsigned hw = std::thread::hardware_concurrency();
         if (!hw) hw = 1;
-        // defaults measured on a 16-CPU share of an MI355X host (profiles/r02/n2_pipeline.md): per window the read selection costs
-        // ~0.35 ms of CPU, diploidGLF ~0.15 ms, packing ~0.05 ms; two engines keep the GPU busy while one of them packs
-        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(4u, std::max(1u, hw / 4))))));
-        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(8u, std::max(1u, hw / 2))))));
+        // defaults measured on a 16-CPU share of an MI355X host (profiles/r03/n2_pipeline.md): per window the read selection costs
+        // 0.10-0.20 ms of CPU, diploidGLF 0.09 ms, packing 0.025 ms; two engines per GPU keep it busy while one of them packs.  They
+        // scale with the number of devices (set below, once --devices is known) up to what the host has.
         // --devices 0,1,...: the engines are dealt out over these GPUs (batches are independent: no exchange between devices)
         std::vector<int> devices;
         {
@@ -231,8 +230,11 @@ int main(int argc, char **argv)
             }
             if (devices.empty()) devices.push_back(0);
         }
-        const int computeThreads = std::max(1, int(num("computeThreads", (hw >= 8 ? 2.0 : 1.0) * double(devices.size()))));
-        const int packThreads = int(num("packThreads", double(std::min(4u, std::max(1u, hw / 4)))));   // host threads of each engine's packing (0: the engine's default)
+        const unsigned nDev = unsigned(devices.size());
+        const int computeThreads = std::max(1, int(num("computeThreads", (hw >= 8 ? 2.0 : 1.0) * double(nDev))));
+        const int packThreads = int(num("packThreads", double(std::min(4u, std::max(1u, hw / (4 * nDev))))));   // host threads of each engine's packing (0: the engine's default)
+        const int reduceThreads = std::max(1, int(num("reduceThreads", double(std::min(4u * nDev, std::max(1u, hw / 4))))));
+        const int prepareThreads = std::max(1, int(num("prepareThreads", double(std::min(8u * nDev, std::max(1u, hw / 2))))));
 
         LibraryCollection libraries;
         if (has("libFile")) {                    // the reference: --libFile switches mapUnmappedReads on (DInDel.cpp:4268-4272)
