@@ -15,7 +15,8 @@ windows/s on: `windows_per_s_incl_copies` (dd_compute_likelihoods with host poin
 and `windows_per_s_end_to_end` (dindel::LikelihoodEngine::computeLikelihoodsBatch on the reference's own
 C++ objects: pack + H2D + kernels + D2H + per-window status scan, records delivered as lazy views), with
 the split and the eager-record rate under `end_to_end`, and `window_loop`: the batched window loop of the diploid analysis (BAM ->
-read selection -> kernels -> diploidGLF -> .glf.txt, host/dindel_gpu) on a synthetic 40,000-window sample the leg writes itself.
+read selection -> kernels -> diploidGLF -> .glf.txt, host/dindel_gpu) on a synthetic 100,000-window sample the leg writes itself
+(`windows_per_s` by the driver's own clock from set-up to the last line written, `steady_windows_per_s` once the pipeline is full).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 10000] [--total-windows T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -158,7 +159,7 @@ def cpu_baseline(pb, params, seconds_target=15.0, faster=False):
                 windows_per_s=n_win / dt)
 
 
-def window_loop_leg(faster, windows=40000):
+def window_loop_leg(faster, windows=100000):
     """The batched window loop (host/dindel_gpu: BAM -> read selection -> GPU likelihoods -> diploidGLF -> .glf.txt) on a synthetic
     sample written by tools/n2_pipeline_bench.py, as a child process; the driver's own clock (set-up to last line written)."""
     import shutil
@@ -167,7 +168,7 @@ def window_loop_leg(faster, windows=40000):
     d = tempfile.mkdtemp(prefix="dd_window_loop_")
     try:
         cmd = [sys.executable, os.path.join(ROOT, "tools", "n2_pipeline_bench.py"), "--windows", str(windows), "--dir", d] + (["--faster"] if faster else [])
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         best = None
         for line in r.stdout.split("\n"):
             if line.startswith("{"):

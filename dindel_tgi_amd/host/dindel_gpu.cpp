@@ -279,7 +279,10 @@ int main(int argc, char **argv)
         std::atomic<int> fatalExit(1);
         BatchPool recycled;
         Channel toPrepare(size_t(prepareThreads) + 1);
-        OrderedChannel toCompute(computeThreads + 1), toReduce(computeThreads + 1);
+        // prepared batches wait for the GPU in file order: room for one per prepare worker, so that a worker that was slow with the batch
+        // at the head of the line (a descheduled thread on a busy host) does not idle the GPU while its successors are ready
+        const long ahead = has("computeAhead") ? long(num("computeAhead", 0)) : long(std::max(computeThreads + 1, prepareThreads));
+        OrderedChannel toCompute(std::max(1L, ahead)), toReduce(computeThreads + 1);
         auto fail = [&](const std::string &s) {
             { std::lock_guard<std::mutex> lk(fatal_m); if (fatal.empty()) fatal = s; }
             toPrepare.abort(); toCompute.abort(); toReduce.abort();

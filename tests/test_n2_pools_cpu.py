@@ -84,3 +84,25 @@ def test_pooled_batches_replay_the_buffer_history(tmp_path):
     a = _dumps(tmp_path, "one_a", s, ["--bamFiles", s["one"]], ["--batchWindows", "5", "--prepareThreads", "2"])
     b = _dumps(tmp_path, "one_b", s, ["--bamFile", s["paths"][0]], ["--batchWindows", "64", "--prepareThreads", "1"])
     assert a == b
+
+
+def test_reference_exit_paths_end_the_run(tmp_path):
+    """Where the reference calls exit() inside getReads (inconsistent mate positions, DInDel.cpp:1134-1137; an unmapped read with two mapped
+    mates, :1180-1183) the window loop must stop with a non-zero status — not write a skipped line and carry on."""
+    if not os.path.exists(DRIVER):
+        pytest.skip("dindel_gpu not built")
+    n_ref = 20000
+    mk = lambda q, pos, flag, mpos, L=60: dict(qname=q, flag=flag, pos=pos, mapq=60, cigar="%dM" % L, seq="ACGT" * (L // 4), qual=[30] * L, mtid=0, mpos=mpos, isize=0, tags={})
+    recs = [mk("f%d" % i, 5000 + 3 * i, 0, -1) for i in range(30)]
+    for r in recs:
+        r["mtid"] = -1
+    recs += [mk("pair", 5010, 1 + 64, 5100), mk("pair", 5090, 1 + 128, 5010)]          # first mate says its mate is at 5100; it is at 5090
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "bad.bam")
+    bw.write_bam(bam, "@SQ\tSN:20\tLN:%d\n" % n_ref, [("20", n_ref)], [(0, r) for r in recs])
+    vf, hf = str(tmp_path / "w.txt"), str(tmp_path / "h.txt")
+    open(vf, "w").write("20 5000 5120 5060,+A\n20 9000 9120 9060,+A\n")
+    open(hf, "w").write("W 1 5000 5120\nH %s\nW 2 9000 9120\nH %s\n" % ("A" * 121, "C" * 121))
+    r = subprocess.run([DRIVER, "--bamFile", bam, "--varFile", vf, "--hapFile", hf, "--outputFile", str(tmp_path / "o"), "--prepareOnly", "--quiet"],
+                       env=_env(), capture_output=True, text=True)
+    assert r.returncode == 1 and "matepos inconsistency!" in r.stderr, (r.returncode, r.stderr)
