@@ -1289,7 +1289,26 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         if ((rc = dev.alloc(&d_read_seq, (size_t)sz.read_bases))) return rc;
         if ((rc = dev.alloc(&d_read_qidx, (size_t)sz.read_bases))) return rc;
         db.read_seq = d_read_seq; db.read_qidx = d_read_qidx;
-    } else { UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases); }
+    } else {
+        // Staged (small) batches whose two big inputs the caller keeps in page-locked, device-addressable memory (the C++ adapter packs
+        // into dd_host_alloc buffers): the kernels read them in place over the link — each (read, haplotype) pair fetches its read once,
+        // ~80 MB per 256-window batch at 8 haplotypes — instead of waiting for a staged copy whose blit kernels share the CUs with the
+        // batch that is running (profiles/r03/window_loop_timeline.txt).  DD_ZERO_COPY_IN=0 switches it off (A/B).
+        static const bool zero_copy_in = !(getenv("DD_ZERO_COPY_IN") && !strcmp(getenv("DD_ZERO_COPY_IN"), "0"));
+        auto mapped_in = [&](const void *host, size_t bytes) -> const void * {
+            if (!zero_copy_in || !host || !bytes) return nullptr;
+            hipPointerAttribute_t a, e;
+            if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+            if (hipPointerGetAttributes(&e, static_cast<const unsigned char *>(host) + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (e.type != hipMemoryTypeHost || !e.devicePointer ||
+                static_cast<unsigned char *>(e.devicePointer) - static_cast<unsigned char *>(a.devicePointer) != (ptrdiff_t)(bytes - 1)) return nullptr;
+            return a.devicePointer;
+        };
+        const void *ms = mapped_in(b->read_seq, (size_t)sz.read_bases), *mq = mapped_in(b->read_qidx, (size_t)sz.read_bases);
+        if (ms && mq) { db.read_seq = static_cast<const char *>(ms); db.read_qidx = static_cast<const uint8_t *>(mq); }
+        else { UP(read_seq, sz.read_bases); UP(read_qidx, sz.read_bases); }
+    }
     UP(read_mqidx, sz.n_reads); UP(read_start, sz.n_reads); UP(read_flags, sz.n_reads);
 #undef UP
     if (b->hap_var_off) {
