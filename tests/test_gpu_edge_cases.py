@@ -437,6 +437,33 @@ def test_multi_device_entry_equals_single_call(lib, faster):
     assert "block 1" in capi.last_error()
 
 
+def test_multi_device_block_of_windows_without_haplotypes(lib):
+    """A block that holds only windows with reads but no haplotypes has no pair to compute; its reads' onHap must still come back 0, as the
+    single-device call (whose onHap kernel covers every read) leaves them — also when there are more devices than windows with pairs."""
+    h = rnd(100)
+    full = lambda start: Window(start, [h, h[:50] + h[52:]], reads_from(h, 12, 40, start0=start))
+    empty = lambda start: Window(start, [], reads_from(h, 9, 40, start0=start))
+    ws = [full(1000), empty(3000), empty(4000), empty(5000), full(7000)]
+    pb = pack(ws)
+    b = pb.ctypes_batch()
+    p = capi.params_cli_defaults()
+    one, res1 = alloc_result(pb, fill=0x55)
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res1), 0) == 0, capi.last_error()
+    assert one["onHap"][12:12 + 27].max() == 0 and one["onHap"][:12].max() == 1
+    for devs in ([0, 0, 0], [0, 0, 0, 0, 0], [0] * 6):
+        many, resm = alloc_result(pb, fill=0x55)
+        d = np.asarray(devs, np.int32)
+        assert lib.dd_compute_likelihoods_multi(C.byref(p), C.byref(b), C.byref(resm), d.ctypes.data_as(capi.c_i32p), len(devs)) == 0, capi.last_error()
+        assert np.array_equal(one["onHap"][:pb.n_reads], many["onHap"][:pb.n_reads]), devs
+        assert np.array_equal(one["ll"][:pb.n_pairs], many["ll"][:pb.n_pairs]), devs
+    # a batch without any pair: onHap zero-filled by the single-device entry too
+    pe = pack([empty(3000), empty(4000)])
+    be = pe.ctypes_batch()
+    none, rese = alloc_result(pe, fill=0x55)
+    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(be), C.byref(rese), 0) == 0, capi.last_error()
+    assert none["onHap"][:pe.n_reads].max() == 0
+
+
 @pytest.mark.parametrize("hs", [30, 59, 60, 61, 62, 100, 118, 120, 121, 123, 124, 125, 126])
 def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     """Round 3: for K <= 2 at D = 6 the right->middle pass carries the LO / RO end states in the generic candidate code
