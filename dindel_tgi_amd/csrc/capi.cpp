@@ -105,7 +105,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
 int reg_limited_waves_per_cu(int K, int Dt, bool gbt)
 {
     if (K <= 2) return (Dt <= 7 || gbt) ? 12 : 8;
-    if (K == 3) return (gbt || Dt <= 7) ? 8 : 4;
+    if (K == 3) return (gbt && Dt <= 7) ? 12 : ((gbt || Dt <= 7) ? 8 : 4);      // round 3: the D = 6 scratch build is held to 168 VGPRs (3 waves/SIMD)
     if (K == 4) return gbt ? 8 : 4;
     return 4;
 }

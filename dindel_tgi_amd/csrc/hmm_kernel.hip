@@ -170,9 +170,11 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // Occupancy target (waves per SIMD) the register allocator is held to.  Measured (tools/ab_point.py): K<=2, D<=7
 // +20 % going from 2 to 3 waves/SIMD (the VALU is the bound and two waves cannot keep it issuing); K=2, D=11
 // needs ~236 VGPRs unspilled: the HBM-scratch build still gains 14 % at 3 waves with spills, the LDS build is
-// LDS-limited to 2 waves/SIMD anyway and loses 7 % to the spills, so it stays at 2.
+// LDS-limited to 2 waves/SIMD anyway and loses 7 % to the spills, so it stays at 2.  K = 3 (round 3, profiles/r03/k3_waves_ab.txt): the
+// D = 6 scratch build at 3 waves/SIMD (168 VGPRs, a few spills outside the sweeps) gains 10-12 % (231.7 -> 207.2 ms per 3,000 windows of
+// 160-bp haplotypes); the D = 11 one loses 14 % to its spills and stays at 2, as does K = 4.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : (((K) <= 4 && (GBT)) ? 2 : 1))
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : (((K) <= 4 && (GBT)) ? 2 : 1))
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
