@@ -391,11 +391,32 @@ int dd_batch_sizes(const dd_batch *b, dd_sizes *out)
     return DD_SUCCESS;
 }
 
-int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[2])
+// byte -> symbol id (dd_build_symbol_lut's rule).  Returns how many distinct haplotype bytes were left without an id (the 27th and later
+// non-ACGTN values in byte order; they map to 31 like a byte no haplotype holds), or a DD_ERR_* code.
+static int assign_symbols(const dd_batch *b, uint8_t *out)
 {
-    if (!b || !win_skip) return fail(DD_ERR_INVALID, "null argument");
-    if (b->n_windows < 0 || !b->win_hap_off || !b->win_read_off || !b->hap_seq_off || !b->read_seq_off)
-        return fail(DD_ERR_INVALID, "null offset array");
+    if (!b || !out || !b->hap_seq_off || !b->win_hap_off) return fail(DD_ERR_INVALID, "null argument");
+    for (int i = 0; i < 256; i++) out[i] = 31;                    // read-only symbol: equal to no haplotype symbol
+    out[(unsigned char)'A'] = 0; out[(unsigned char)'C'] = 1; out[(unsigned char)'G'] = 2; out[(unsigned char)'T'] = 3;
+    out[(unsigned char)'N'] = 4;
+    bool seen[256] = {false};
+    const int64_t n_haps = b->n_windows > 0 ? b->win_hap_off[b->n_windows] : 0;
+    const int64_t nb = n_haps > 0 ? b->hap_seq_off[n_haps] : 0;
+    if (nb > 0 && !b->hap_seq) return fail(DD_ERR_INVALID, "null input array");
+    for (int64_t i = 0; i < nb; i++) seen[(unsigned char)b->hap_seq[i]] = true;
+    int next = 5, left = 0;
+    for (int c = 0; c < 256; c++) {
+        if (!seen[c] || c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') continue;
+        if (next > 30) { left++; continue; }
+        out[c] = (uint8_t)next++;
+    }
+    return left;
+}
+
+// The screen proper.  sym_lut (may be NULL: lengths only) is assign_symbols' table; with_symbols: windows whose haplotypes hold a byte
+// that got no id are skipped too (main model only: the --faster kernel compares the bytes themselves).
+static int screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[2], const uint8_t *sym_lut, bool with_symbols)
+{
     int n_skip = 0, mh = 0, mr = 0;
     for (int w = 0; w < b->n_windows; w++) {
         int wh = 0, wr = 0;
@@ -410,6 +431,13 @@ int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[
             if (len < 1 || len > DD_MAX_READ_LEN) bad = true;
             if (len > wr) wr = len;
         }
+        if (with_symbols && !bad) {
+            const int64_t from = b->hap_seq_off[b->win_hap_off[w]], to = b->hap_seq_off[b->win_hap_off[w + 1]];
+            for (int64_t i = from; i < to && !bad; i++) {
+                const unsigned char c = (unsigned char)b->hap_seq[i];
+                if (sym_lut[c] == 31) bad = true;          // a haplotype byte is never 31 unless it was left without an id
+            }
+        }
         win_skip[w] = bad ? 1 : 0;
         if (bad) { n_skip++; continue; }
         if (b->win_hap_off[w + 1] > b->win_hap_off[w] && b->win_read_off[w + 1] > b->win_read_off[w]) {   // windows with pairs
@@ -419,6 +447,17 @@ int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[
     }
     if (max_len_out) { max_len_out[0] = mh; max_len_out[1] = mr; }
     return n_skip;
+}
+
+int dd_screen_windows(const dd_batch *b, uint8_t *win_skip, int32_t max_len_out[2])
+{
+    if (!b || !win_skip) return fail(DD_ERR_INVALID, "null argument");
+    if (b->n_windows < 0 || !b->win_hap_off || !b->win_read_off || !b->hap_seq_off || !b->read_seq_off)
+        return fail(DD_ERR_INVALID, "null offset array");
+    uint8_t lut[256];
+    const int left = assign_symbols(b, lut);
+    if (left < 0) return left;
+    return screen_windows(b, win_skip, max_len_out, lut, left > 0);
 }
 
 int dd_batch_offsets(const dd_batch *b, int64_t *win_pair_off, int64_t *win_hpos_off, int64_t *win_varcov_off)
@@ -471,22 +510,8 @@ int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log9
 
 int dd_build_symbol_lut(const dd_batch *b, uint8_t *out)
 {
-    if (!b || !out || !b->hap_seq_off || !b->win_hap_off) return fail(DD_ERR_INVALID, "null argument");
-    for (int i = 0; i < 256; i++) out[i] = 31;                    // read-only symbol: equal to no haplotype symbol
-    out[(unsigned char)'A'] = 0; out[(unsigned char)'C'] = 1; out[(unsigned char)'G'] = 2; out[(unsigned char)'T'] = 3;
-    out[(unsigned char)'N'] = 4;
-    bool seen[256] = {false};
-    const int64_t n_haps = b->n_windows > 0 ? b->win_hap_off[b->n_windows] : 0;
-    const int64_t nb = n_haps > 0 ? b->hap_seq_off[n_haps] : 0;
-    if (nb > 0 && !b->hap_seq) return fail(DD_ERR_INVALID, "null input array");
-    for (int64_t i = 0; i < nb; i++) seen[(unsigned char)b->hap_seq[i]] = true;
-    int next = 5;
-    for (int c = 0; c < 256; c++) {
-        if (!seen[c] || c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') continue;
-        if (next > 30) return fail(DD_ERR_UNSUPPORTED, "more than 26 distinct non-ACGTN byte values in the haplotypes of one batch");
-        out[c] = (uint8_t)next++;
-    }
-    return DD_SUCCESS;
+    const int left = assign_symbols(b, out);
+    return left < 0 ? left : DD_SUCCESS;        // bytes left without an id: their windows are dd_screen_windows' business
 }
 
 int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, const double *mapq_table, int n_mapq, double *out)
@@ -1152,14 +1177,15 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     // windows whose shape the kernels do not cover are skipped one by one (DD_PAIR_UNSUPPORTED), not the batch
     std::vector<uint8_t> win_skip((size_t)b->n_windows);
     int32_t ok_max[2] = {0, 0};
-    const int n_skip = dd_screen_windows(b, win_skip.data(), ok_max);
-    if (n_skip < 0) return n_skip;
+    if (!b->hap_seq_off || !b->read_seq_off) return fail(DD_ERR_INVALID, "null offset array");
+    uint8_t sym_lut[256];
+    const int sym_left = assign_symbols(b, sym_lut);     // > 0: more than 26 distinct non-ACGTN haplotype bytes in the batch
+    if (sym_left < 0) return sym_left;
+    clk.mark("symbols");
+    const int n_skip = screen_windows(b, win_skip.data(), ok_max, sym_lut, sym_left > 0 && model == MODEL_FBMAXERR);
     sz.max_hap_len = ok_max[0] > 0 ? ok_max[0] : 1;      // planning maxima: the windows that are computed
     sz.max_read_len = ok_max[1] > 0 ? ok_max[1] : 1;
     clk.mark("screen");
-    uint8_t sym_lut[256];
-    if ((rc = dd_build_symbol_lut(b, sym_lut))) return rc;
-    clk.mark("symbols");
     std::vector<double> lib_logprob, lib_log95;
     if (p->mapUnmappedReads && model == MODEL_FBMAXERR) {
         if (!b->read_mate_pos || !b->read_mate_len || !b->read_lib)

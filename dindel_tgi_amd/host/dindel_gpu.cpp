@@ -136,6 +136,17 @@ public:
         cv_.notify_all();
         return true;
     }
+    bool tryPop(BatchPtr &b)             // the next batch if it is already here; never waits
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        std::map<long, BatchPtr>::iterator it = held_.find(next_);
+        if (aborted_ || it == held_.end()) return false;
+        b = std::move(it->second);
+        held_.erase(it);
+        next_++;
+        cv_.notify_all();
+        return true;
+    }
     void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; cv_.notify_all(); }
     void abort() { std::lock_guard<std::mutex> lk(m_); aborted_ = true; held_.clear(); cv_.notify_all(); }
 private:
@@ -173,7 +184,7 @@ int main(int argc, char **argv)
             "  model:    [--faster] [--libFile F] [--filterHaplotypes] [--outputRealignedBAM] [--varFileIsOneBased]\n"
             "            [--maxRead N] [--maxReadLength N] [--minReadOverlap N] [--mapQualThreshold X] [--filterReadAux STR] [--pError X] [--pMut X] [--maxLengthIndel N]\n"
             "            [--flankRefSeq N] [--flankMaxMismatch N] [--priorSNP X] [--priorIndel X] [--capMapQualThreshold X] [--capMapQualFast X] [--maxHapReadProd N]\n"
-            "  running:  [--batchWindows N] [--device D | --devices D0,D1,...] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N]\n"
+            "  running:  [--batchWindows N] [--mergeBatches N] [--device D | --devices D0,D1,...] [--prepareThreads N] [--computeThreads N] [--packThreads N] [--reduceThreads N]\n"
             "            [--quiet] [--timing] [--prepareOnly]\n"
             "  files:    --varFile: the reference's window file; --hapFile: W / H / V / A records (host/window_io.hpp)\n";
         return 0;
@@ -282,7 +293,13 @@ int main(int argc, char **argv)
         // prepared batches wait for the GPU in file order: room for one per prepare worker, so that a worker that was slow with the batch
         // at the head of the line (a descheduled thread on a busy host) does not idle the GPU while its successors are ready
         const long ahead = has("computeAhead") ? long(num("computeAhead", 0)) : long(std::max(computeThreads + 1, prepareThreads));
-        OrderedChannel toCompute(std::max(1L, ahead)), toReduce(computeThreads + 1);
+        // batches that are already waiting when an engine becomes free ride in one launch with the batch it takes (up to --mergeBatches of
+        // them): the host stages keep their small batches, the GPU gets the larger launches it runs better (42.5 us per window in a launch of
+        // 256 windows, 41.3 in one of 1,024, and one kernel boundary instead of four)
+        // (default 4; 2 when the per-base alignments come back too — --faster, --outputRealignedBAM —: the page-locked result blocks of such a
+        // launch are 0.4 GB each, and making them costs a 100,000-window run more than the launches save it)
+        const int mergeBatches = std::max(1, int(num("mergeBatches", (has("faster") || has("outputRealignedBAM")) ? 2 : 4)));
+        OrderedChannel toCompute(std::max(1L, ahead)), toReduce(long(computeThreads) * mergeBatches + 1);
         auto fail = [&](const std::string &s) {
             { std::lock_guard<std::mutex> lk(fatal_m); if (fatal.empty()) fatal = s; }
             toPrepare.abort(); toCompute.abort(); toReduce.abort();
@@ -360,6 +377,8 @@ int main(int argc, char **argv)
             t_unpack_of(size_t(computeThreads), 0.0);
         std::vector<std::thread> computeWorkers;
         std::atomic<int> computeLeft(computeThreads);
+        std::atomic<long> nLaunches(0);
+        std::vector<double> t_ready_of(size_t(computeThreads), 0.0);         // when each engine had its device context, arena and streams
         for (int ct = 0; ct < computeThreads; ct++) computeWorkers.push_back(std::thread([&, ct]() {
             BatchPtr b;
             try {
@@ -368,25 +387,52 @@ int main(int argc, char **argv)
                 // diploidGLF reads scalars and covered flags only; the --faster model's indel count (DInDel.cpp:3529) needs hpos
                 engine.setKeepAlignments(faster || realignedBAM);
                 if (packThreads > 0) engine.setHostThreads(packThreads);
-                if (!prepareOnly) engine.warmUp(size_t(batchWindows) * 8 * 200);     // while the first batches are being prepared
-                while (toCompute.pop(b)) {
+                if (!prepareOnly) engine.warmUp(size_t(batchWindows) * size_t(mergeBatches) * 8 * 200);     // while the first batches are being prepared
+                t_ready_of[size_t(ct)] = seconds_since(t_start);
+                std::vector<BatchPtr> group;
+                std::vector<WindowJob> merged;
+                bool open = true;
+                while (open && toCompute.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                    Batch &B = *b;
-                    B.jobOf.assign(B.tasks.size(), size_t(-1));
-                    for (size_t i = 0; i < B.tasks.size(); i++) if (!B.tasks[i].skipped) {
-                        WindowJob J;
-                        J.haps = B.tasks[i].haps; J.reads = &B.tasks[i].reads; J.leftPos = B.tasks[i].leftPos; J.rightPos = B.tasks[i].rightPos;
-                        B.jobOf[i] = B.jobs.size();
-                        B.jobs.push_back(J);
+                    group.clear();
+                    group.push_back(std::move(b));
+                    while (int(group.size()) < mergeBatches && toCompute.tryPop(b)) group.push_back(std::move(b));
+                    size_t nJobs = 0;
+                    for (size_t g = 0; g < group.size(); g++) {
+                        Batch &B = *group[g];
+                        B.jobOf.assign(B.tasks.size(), size_t(-1));
+                        for (size_t i = 0; i < B.tasks.size(); i++) if (!B.tasks[i].skipped) {
+                            WindowJob J;
+                            J.haps = B.tasks[i].haps; J.reads = &B.tasks[i].reads; J.leftPos = B.tasks[i].leftPos; J.rightPos = B.tasks[i].rightPos;
+                            B.jobOf[i] = B.jobs.size();
+                            B.jobs.push_back(J);
+                        }
+                        nJobs += B.jobs.size();
                     }
-                    if (!B.jobs.empty() && !prepareOnly) {
-                        if (faster) engine.computeLikelihoodsFasterBatch(B.jobs); else engine.computeLikelihoodsBatch(B.jobs);
+                    if (nJobs > 0 && !prepareOnly) {
+                        // one call for the group: the jobs travel through one vector and go back to their batches with their views
+                        std::vector<WindowJob> *jobs = &group[0]->jobs;
+                        if (group.size() > 1) {
+                            merged.clear();
+                            for (size_t g = 0; g < group.size(); g++)
+                                for (size_t j = 0; j < group[g]->jobs.size(); j++) merged.push_back(std::move(group[g]->jobs[j]));
+                            jobs = &merged;
+                        }
+                        if (faster) engine.computeLikelihoodsFasterBatch(*jobs); else engine.computeLikelihoodsBatch(*jobs);
+                        if (group.size() > 1) {
+                            size_t at = 0;
+                            for (size_t g = 0; g < group.size(); g++)
+                                for (size_t j = 0; j < group[g]->jobs.size(); j++) group[g]->jobs[j] = std::move(merged[at++]);
+                            merged.clear();
+                        }
                         t_pack_of[size_t(ct)] += engine.lastPackSeconds; t_device_of[size_t(ct)] += engine.lastDeviceSeconds;
                         t_unpack_of[size_t(ct)] += engine.lastUnpackSeconds;
+                        nLaunches++;
                     }
                     t_compute_of[size_t(ct)] += seconds_since(t0);
-                    if (!toReduce.push(b)) break;
+                    for (size_t g = 0; g < group.size() && open; g++) if (!toReduce.push(group[g])) open = false;
                 }
+                group.clear();
                 b.reset();
                 if (--computeLeft == 0) toReduce.close();
                 // the batches still being reduced hold views into this engine's result blocks: wait for the writer
@@ -567,6 +613,17 @@ int main(int argc, char **argv)
             while (from + 1 < progress.size() && progress[from].second * 5 < nWindows) from++;
             if (from + 1 < progress.size() && progress.back().first > progress[from].first)
                 std::cout << " steady_windows_per_s=" << double(progress.back().second - progress[from].second) / (progress.back().first - progress[from].first);
+            std::cout << " launches=" << nLaunches.load();
+            // when the first batch and the first 1 / 5 / 20 / 50 / 100 % of the windows were written (seconds since start)
+            std::cout << " engines_ready_at=";
+            for (size_t i = 0; i < t_ready_of.size(); i++) std::cout << (i ? "," : "") << t_ready_of[i];
+            std::cout << " written_at=";
+            size_t at = 0;
+            if (!progress.empty()) std::cout << progress[0].first << "(first)";
+            for (int pc : {1, 5, 20, 50, 100}) {
+                while (at + 1 < progress.size() && progress[at].second * 100 < nWindows * pc) at++;
+                if (!progress.empty()) std::cout << "/" << progress[at].first;
+            }
             std::cout << std::endl;
         }
     } catch (std::string &s) {

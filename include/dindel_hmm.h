@@ -190,7 +190,8 @@ typedef struct dd_sizes {
 int dd_batch_sizes(const dd_batch *b, dd_sizes *out);
 
 /* Per-window shape screen: win_skip[w] = 1 iff window w holds a haplotype longer than DD_MAX_HAP_LEN, a read longer than
- * DD_MAX_READ_LEN, or an empty haplotype / read; its pairs get DD_PAIR_UNSUPPORTED instead of failing the whole batch.
+ * DD_MAX_READ_LEN, an empty haplotype / read, or a haplotype byte that dd_build_symbol_lut could not number (more than 26
+ * distinct non-ACGTN values in the batch); its pairs get DD_PAIR_UNSUPPORTED instead of failing the whole batch.
  * max_len_out[2] (may be NULL) = longest haplotype / read among the windows that pass.  Returns the number of skipped
  * windows (>= 0) or a DD_ERR_* code.  dd_compute_likelihoods does this by itself; callers of dd_launch_device upload
  * win_skip (dd_device_batch.win_skip) and plan with the returned maxima. */
@@ -236,7 +237,8 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual,
 /* Bases are compared as characters, as in the reference (hap[y]==nuc || hap[y]=='N', ObservationModelFB.cpp:246): any
  * byte may occur in reads and haplotypes (IUPAC codes, soft-masked lower case).  This builds the byte -> symbol-id table
  * the main kernel uses (A,C,G,T -> 0..3, N -> 4, other bytes present in a haplotype of the batch -> 5..30, the rest -> 31);
- * out[256].  More than 26 distinct non-ACGTN haplotype bytes in one batch -> DD_ERR_UNSUPPORTED. */
+ * out[256].  With more than 26 distinct non-ACGTN haplotype bytes in one batch the values beyond the 26th (in byte order) get no id:
+ * dd_screen_windows flags the windows that hold one (DD_PAIR_UNSUPPORTED for those windows, not an error of the call). */
 int dd_build_symbol_lut(const dd_batch *b, uint8_t *out);
 
 /* log(Library::getProb(x)) for every entry of dd_batch.lib_prob (logprob_out[lib_off[n_libs]]) and

@@ -107,10 +107,6 @@ def test_no_cpu_fallback_and_validation(lib):
         assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res), 0) == capi.DD_ERR_NO_DEVICE
         assert "no CPU fallback" in capi.last_error()
     # validation happens before any device work
-    bad = _one_window(hap="".join(chr(c) for c in range(97, 97 + 27)))      # 27 distinct non-ACGTN haplotype bytes
-    bb = bad.ctypes_batch()
-    assert lib.dd_compute_likelihoods(C.byref(p), C.byref(bb), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
-    assert "26 distinct" in capi.last_error()
     p2 = capi.params_cli_defaults(); p2.mapUnmappedReads = 1                 # needs the mate / library arrays
     assert lib.dd_compute_likelihoods(C.byref(p2), C.byref(b), C.byref(res), 0) == capi.DD_ERR_INVALID
     assert "mapUnmappedReads" in capi.last_error()
@@ -252,6 +248,29 @@ def test_screen_windows_flags_only_the_offending_windows(lib):
     pb2 = pack([limit, good])
     assert lib.dd_screen_windows(C.byref(pb2.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 0
     assert list(mx) == [766, 1024]
+
+
+def test_screen_windows_odd_bytes_beyond_the_symbol_table(lib):
+    """The main kernel's symbol table holds 26 non-ACGTN byte values per batch (in byte order).  Windows whose haplotypes use a value that
+    got none are flagged one by one (round 2 failed the whole call); with 26 or fewer nothing is flagged, whatever the bytes are."""
+    odd = "".join(chr(c) for c in range(97, 97 + 29) if chr(c) not in "acgtn")           # b d e f ... : 24 lower-case letters + '{' '|' '}'
+    assert len(set(odd)) == 24
+    rd = [ReadRec("ACGTAC", [0.999] * 6, 0.9999, 1000)]
+    plain = Window(1000, ["ACGTACGTNN"], rd)
+    w24 = Window(1000, ["ACGT" + odd], rd)
+    low = Window(1000, ["ACGT!#"], rd)                                                     # two more, small byte values: they get ids 5, 6
+    high = Window(1000, ["ACGT~"], rd)                                                     # the 27th distinct value in byte order
+    both = Window(1000, ["AC~GT", "ACGT"], rd)
+    skip = np.full(8, 7, np.uint8)
+    mx = (C.c_int32 * 2)()
+    pb = pack([plain, w24, low])                                                           # 26 distinct: everything fits
+    assert lib.dd_screen_windows(C.byref(pb.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 0
+    pb = pack([plain, w24, low, high, plain, both])                                        # 27: only the windows holding '~' go
+    assert lib.dd_screen_windows(C.byref(pb.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 2
+    assert skip[:6].tolist() == [0, 0, 0, 1, 0, 1] and list(mx) == [28, 6]
+    lut = np.zeros(256, np.uint8)
+    assert lib.dd_build_symbol_lut(C.byref(pb.ctypes_batch()), lut.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert int(lut[ord("!")]) == 5 and int(lut[ord("#")]) == 6 and int(lut[ord("}")]) == 30 and int(lut[ord("~")]) == 31
 
 
 def test_partition_windows_balances_cells(lib):

@@ -405,6 +405,58 @@ def test_unsupported_window_fails_alone(lib, faster):
 
 
 @pytest.mark.parametrize("faster", [False, True])
+def test_window_with_bytes_beyond_the_symbol_table_fails_alone(lib, faster):
+    """More than 26 distinct non-ACGTN byte values in the haplotypes of a batch: the main kernel's symbol table cannot number them all, and
+    the windows that hold an unnumbered value get DD_PAIR_UNSUPPORTED — the other windows equal the oracle (round 2 failed the call).  The
+    --faster kernel compares the bytes themselves and computes every window."""
+    import torch
+    from dindel_tgi_amd.batch import pair_slices
+    from dindel_tgi_amd.device import DeviceBatch
+    p = capi.params_cli_defaults()
+    hapA, hapB = rnd(110), rnd(140)
+    odd = "".join(chr(c) for c in range(98, 127) if chr(c) not in "cgtn")                 # 25 values b ... ~
+    assert len(set(odd)) == 25
+    good1 = Window(1000, [hapA, hapA[:50] + hapA[52:]], reads_from(hapA, 9, 70))
+    hapLow, hapMarks, hapTilde = hapB[:60] + odd[:24] + hapB[60:], hapA[:30] + "!#" + hapA[30:], hapB[:70] + "~" + hapB[70:]
+    lower = Window(1000, [hapLow, hapB], reads_from(hapLow, 6, 80))                                # numbered values only
+    marks = Window(1000, [hapMarks], reads_from(hapMarks, 5, 60))                                  # two small values: numbered first
+    tilde = Window(1000, [hapB, hapTilde], reads_from(hapTilde, 7, 90))                            # '~' is the 27th in byte order
+    ws = [good1, lower, marks, tilde, good1]
+    pb = pack(ws)
+    want = _oracle.batch(p, pb, nthreads=4, faster=faster)
+    bad = [] if faster else [3]
+
+    def check_result(got):
+        for w in range(len(ws)):
+            p0, H, R, h0, SL, _ = pair_slices(pb, w)
+            r0 = int(pb.a["win_read_off"][w])
+            if w in bad:
+                assert (got["status"][p0:p0 + H * R] == capi.DD_PAIR_UNSUPPORTED).all()
+                assert (got["ll"][p0:p0 + H * R] == 0).all() and not got["onHap"][r0:r0 + R].any()
+                continue
+            for k in ("ll", "llOn", "llOff", "mLogBQ", "status", "offHap", "offHapHMQ", "numIndels", "firstBase", "lastBase"):
+                assert np.array_equal(got[k][p0:p0 + H * R], want[k][p0:p0 + H * R]), (w, k)
+            assert np.array_equal(got["hpos"][h0:h0 + H * SL], want["hpos"][h0:h0 + H * SL]), w
+            assert np.array_equal(got["onHap"][r0:r0 + R], want["onHap"][r0:r0 + R]), w
+
+    arrs, res = alloc_result(pb, fill=None)
+    fn = lib.dd_compute_likelihoods_faster if faster else lib.dd_compute_likelihoods
+    assert fn(C.byref(p), C.byref(pb.ctypes_batch()), C.byref(res), 0) == 0, capi.last_error()
+    check_result(arrs)
+    if not faster:                                       # device-pointer path: dd_screen_windows' flags travel with the batch
+        dev = DeviceBatch(pb, p, "cuda:0")
+        assert dev.n_skipped == 1
+        dev.launch()
+        torch.cuda.synchronize()
+        check_result(dev.results())
+        # without '~' everything is numbered and computed
+        pb3 = pack(ws[:3])
+        arrs, res = alloc_result(pb3, fill=None)
+        assert fn(C.byref(p), C.byref(pb3.ctypes_batch()), C.byref(res), 0) == 0, capi.last_error()
+        assert (arrs["status"][:pb3.n_pairs] != capi.DD_PAIR_UNSUPPORTED).all()
+
+
+@pytest.mark.parametrize("faster", [False, True])
 def test_multi_device_entry_equals_single_call(lib, faster):
     """dd_compute_likelihoods_multi with devices = {0, 0} / {0, 0, 0} (two / three window blocks, each under its own host
     thread, arena and streams, concurrently on the one GPU of this box) writes exactly the single call's arrays."""

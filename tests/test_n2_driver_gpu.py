@@ -401,6 +401,10 @@ def test_driver_ragged_sample_is_batching_invariant(tmp_path):
         b = open(run_driver(scene, "rg_b", "--batchWindows", "1", "--prepareThreads", "1", "--computeThreads", "1", "--reduceThreads", "1", *model)[0]).read()
         c = open(run_driver(scene, "rg_c", "--batchWindows", "23", "--prepareThreads", "3", "--computeThreads", "3", "--reduceThreads", "5", *model)[0]).read()
         assert a == b == c
+        # engines that find further batches waiting put them into the same launch (--mergeBatches, default 4 / 2): off, and wide
+        d1 = open(run_driver(scene, "rg_d", "--batchWindows", "5", "--mergeBatches", "1", *model)[0]).read()
+        d2 = open(run_driver(scene, "rg_e", "--batchWindows", "5", "--mergeBatches", "9", "--computeThreads", "1", *model)[0]).read()
+        assert a == d1 == d2
         rows = [l.split(" ") for l in a.split("\n")[1:] if l]
         assert len({l[1] for l in rows if l[2] == "dip.map"}) > 350                       # nearly every window is called
 

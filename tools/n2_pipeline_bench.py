@@ -7,6 +7,7 @@ per window drawn from the reference and one variant haplotype (a heterozygous si
     python tools/n2_pipeline_bench.py [--windows 2000] [--reads 200] [--batch 256] [--dir /tmp/n2bench] [--faster]
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -218,12 +219,13 @@ for cfg in configs:
         if out.returncode != 0:
             print(out.stderr[-2000:])
             sys.exit(1)
-        rows = open(os.path.join(args.dir, "out.glf.txt")).read().split("\n")
+        text = open(os.path.join(args.dir, "out.glf.txt")).read()
+        rows = text.split("\n")
         calls = sum(1 for l in rows if " dip.map " in l)
         skipped = sum(1 for l in rows[1:] if l and not l.startswith("ok "))
         timing = [l for l in out.stdout.split("\n") if l.startswith("timing:")]
         print(json.dumps(dict(rep=rep, windows=args.windows, options=" ".join(cfg), seconds=round(dt, 3), windows_per_s=round(args.windows / dt, 1),
-                              dip_map_lines=calls, skipped=skipped, driver=timing[-1] if timing else None)), flush=True)
+                              dip_map_lines=calls, skipped=skipped, md5=hashlib.md5(text.encode()).hexdigest(), driver=timing[-1] if timing else None)), flush=True)
 
 if args.vcf:
     lst = os.path.join(args.dir, "glf_files.txt")
