@@ -26,8 +26,11 @@ capi.LIB_PATH = so
 lib = capi.load()
 from dindel_tgi_amd.device import DeviceBatch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-pb = synth.generate(n, H=8, R=200, L=100, hap_len=120, seed=3)
+# shape: PP_SHAPE="H R L hap maxLengthDel" (default: configs[1]); the stamped build must hold the (K, D) the plan picks (DD_ONLY)
+H, R, L, hap, mld = [int(x) for x in os.environ.get("PP_SHAPE", "8 200 100 120 5").split()]
+pb = synth.generate(n, H=H, R=R, L=L, hap_len=hap, seed=3)
 params = capi.params_cli_defaults()
+params.maxLengthDel = mld
 dev = DeviceBatch(pb, params, "cuda:0")
 dbg = torch.zeros(16, dtype=torch.int64, device="cuda:0")
 lib.dd_debug_set_stamp_buffer(C.c_void_p(dbg.data_ptr()))
@@ -40,3 +43,4 @@ tot = v[:8].sum()
 for i, nme in enumerate(names):
     print("%-18s %14.0f cycles  %5.1f %%   %9.0f cycles/pair" % (nme, v[i], 100 * v[i] / tot, v[i] / pb.n_pairs))
 print("total %.0f cycles/pair (wave time, incl. stamp overhead)" % (tot / pb.n_pairs))
+print("kernel", capi.last_launch(), "shape", (H, R, L, hap, mld))

@@ -24,5 +24,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc pass $i done"
 done
 python3 $R/tools/pmc_summary.py $OUT "$KSUB" $OUT/bench.json > $OUT/pmc.json
+python3 $R/tools/refresh_traffic.py $OUT/bench.json $OUT/pmc.json "profiles/<round>/<tag>_pmc.json" || true   # the line was written before these passes
 rm -rf $OUT/trace $OUT/pmc_[0-9] $OUT/*.log
 cat $OUT/pmc.json
