@@ -22,6 +22,9 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
     unsigned u[8];
     float f[8];
     for (int i = 0; i < 8; i++) { a[i] = seed * (i + 1) + threadIdx.x * 1e-9; b[i] = -seed * (i + 2); u[i] = threadIdx.x + i; f[i] = float(i) + float(seed); }
+    if (OP >= 14 && OP <= 16)
+        asm volatile("v_mov_b64 v[100:101], %0\n v_mov_b64 v[108:109], %1\n v_mov_b32 v106, 0\n v_mov_b32 v114, 0" : : "v"(b[0]), "v"(b[1])
+                     : "v100", "v101", "v106", "v108", "v109", "v114");
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (LANES == 64 || (threadIdx.x & 63) < LANES)
@@ -82,6 +85,33 @@ __global__ void __launch_bounds__(1024) rate_kernel(double *out, unsigned long l
 #undef X
             } else if (OP == 13) {
 #define X(i) asm volatile("v_cmp_ge_f64 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(a[i]), "+v"(u[i]) : "v"(b[i]), "v"(u[(i + 1) & 7]) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 14) {     // one candidate of the right->middle pass as the compiler emits it: ONE chain through `best` (v[100:101]); 8 per r
+                                       // (fixed physical registers: the selects work on the halves of the 64-bit values)
+#define X(i) asm volatile("v_add_f64 v[104:105], %0, %1\n v_add_f64 v[104:105], v[104:105], %2\n v_add_f64 v[102:103], v[100:101], %3\n" \
+                          "v_cmp_gt_f64 vcc, v[104:105], v[102:103]\n s_nop 1\n" \
+                          "v_cndmask_b32 v101, v101, v105, vcc\n v_cndmask_b32 v100, v100, v104, vcc\n v_cndmask_b32 v106, v106, %4, vcc" \
+                          : : "v"(a[1 + (i % 3)]), "v"(b[1 + (i % 5)]), "v"(b[6]), "v"(seed), "v"(u[1 + (i & 3)]) \
+                          : "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106");
+                REP8(X)
+#undef X
+            } else if (OP == 15) {     // the same work for TWO positions, the two chains (v[100:101], v[108:109]) interleaved, compare results in SGPR pairs:
+                                       // two VALU instructions lie between a compare and the first select that reads it, no s_nop
+#define X(i) asm volatile("v_add_f64 v[104:105], %0, %1\n v_add_f64 v[112:113], %0, %2\n v_add_f64 v[104:105], v[104:105], %2\n v_add_f64 v[112:113], v[112:113], %1\n" \
+                          "v_add_f64 v[102:103], v[100:101], %3\n v_cmp_gt_f64 s[20:21], v[104:105], v[102:103]\n" \
+                          "v_add_f64 v[110:111], v[108:109], %3\n v_cmp_gt_f64 s[22:23], v[112:113], v[110:111]\n" \
+                          "v_cndmask_b32 v101, v101, v105, s[20:21]\n v_cndmask_b32 v100, v100, v104, s[20:21]\n v_cndmask_b32 v106, v106, %4, s[20:21]\n" \
+                          "v_cndmask_b32 v109, v109, v113, s[22:23]\n v_cndmask_b32 v108, v108, v112, s[22:23]\n v_cndmask_b32 v114, v114, %4, s[22:23]" \
+                          : : "v"(a[2 + (i % 3)]), "v"(b[2 + (i % 5)]), "v"(b[7]), "v"(seed), "v"(u[2 + (i & 3)]) \
+                          : "s20", "s21", "s22", "s23", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v108", "v109", "v110", "v111", "v112", "v113", "v114");
+                REP8(X)
+#undef X
+            } else if (OP == 16) {     // one candidate of the left->middle pass: three adds, compare, max, one select (chain through v_max_f64 only)
+#define X(i) asm volatile("v_add_f64 v[104:105], %0, %1\n v_add_f64 v[104:105], v[104:105], %2\n v_add_f64 v[104:105], v[104:105], %3\n" \
+                          "v_cmp_nge_f64 vcc, v[104:105], v[100:101]\n v_max_f64 v[100:101], v[100:101], v[104:105]\n v_cndmask_b32 v106, v106, %4, vcc" \
+                          : : "v"(a[1 + (i % 3)]), "v"(b[1 + (i % 5)]), "v"(b[6]), "v"(seed), "v"(u[1 + (i & 3)]) \
+                          : "vcc", "v100", "v101", "v104", "v105", "v106");
                 REP8(X)
 #undef X
             }
@@ -145,6 +175,10 @@ int main()
     run<11>("v_min_u32", 1);
     run<12>("v_pk_add_f32", 1);
     run<13>("cmp_ge_f64+cndmask (2)", 2);
+    // whole candidates (figures are per INSTRUCTION; x 7 / x 6 / x 6 for one candidate; the s_nop of the first is not counted as one)
+    run<14>("Inc candidate, one chain (7)", 7);
+    run<15>("Inc candidate x2, interleaved (14)", 14);
+    run<16>("Dec candidate (6)", 6);
     // sparse EXEC masks: does a wave64 instruction with few enabled lanes cost less?
     run<0, 32>("v_add_f64, lanes 0-31 enabled", 1);
     run<0, 16>("v_add_f64, lanes 0-15 enabled", 1);
