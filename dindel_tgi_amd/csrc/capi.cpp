@@ -906,9 +906,11 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the build with the end states folded into the generic candidate code (hmm_kernel.hip, FOLD): K <= 2, D build 6, LDS
-    // back-pointers, and every haplotype of this launch leaves position 64 K - 1 idle (numS <= 64 K - 1)
-    const bool fold = !pl.gbt && Dt == 6 && K <= 2 && 64 * K >= cls_hap + 3 && !getenv("DD_NO_FOLD");
+    // the build with the end states folded into the generic candidate code (hmm_kernel.hip, FOLD): K <= 2 at D build 6 with LDS
+    // back-pointers, K = 2 at D build 6 with scratch back-pointers, K = 2 at D build 11 with LDS back-pointers — and every haplotype
+    // of this launch leaves position 64 K - 1 idle (numS <= 64 K - 1)
+    const bool fold_build = pl.gbt ? (K == 2 && Dt == 6) : ((K <= 2 && Dt == 6) || (K == 2 && Dt == 11));     // the builds measured to gain from it
+    const bool fold = fold_build && 64 * K >= cls_hap + 3 && !getenv("DD_NO_FOLD");
     g_last_fold = fold ? 1 : 0;
     HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, fold, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ && (!lc || lc->run_onhap)) HIP_TRY(ddk::launch_onhap(A, st));

@@ -355,10 +355,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     //   LO needs position NP-1 idle (numS <= NP-1: the host launches the FOLD build only for length classes with 64 K >= Hs + 3,
     //   capi.cpp); RO's two slots must not reach LO's position, so RO is folded only when numS <= NP-3 as well — otherwise its
     //   one-lane block runs as in the other builds.
-    //   What it buys (profiles/r03/fold_ab.txt): the sweep's loop body goes from 214 to 188 instructions (fp64 89 -> 70), the kernel
-    //   gains 2.3-3.3 % at K <= 2 / D = 6 (245.8 -> 240.3 ms per 6,000 windows of configs[1]) — less than the count suggests, because
-    //   the fold adds two adds, a dozen moves and five masked 8-byte LDS stores in front of the slice exchange — and nothing or less
-    //   where the sweep is longer (D = 11, K >= 3, the LEAN builds: -1 ... -7 %), so only those two builds carry it.
+    //   What it buys (profiles/r03/fold_ab.txt, fold_publish_ab.txt): the sweep's loop body goes from 214 to 188 instructions (fp64
+    //   89 -> 70) and the kernel gained 2.3-3.3 % at K <= 2 / D = 6 with the first form of the stores in front of the slice exchange
+    //   (two masked blocks, a dozen moves, spilled-SGPR addresses: 245.8 -> 240.3 ms per 6,000 windows of configs[1]); with the one
+    //   masked block below (197 instructions) another 2.1 % (-> 235.9 ms).  It now also pays for K = 2 at D = 11 with LDS back-pointers
+    //   (+1.4 %) and for the K = 2 scratch build at D = 6 (long reads, +3-4 %); the D = 11 scratch build still loses 4.5 % and K >= 3
+    //   would need state 1's pair from another slot than the lane's last, so those keep the one-lane blocks (capi.cpp picks).
     const bool foldRO = foldLO && kRO == K - 1 && numS <= NP - 3;
     constexpr int k1 = 1 % K;                       // state 1 lives in lane 1 / K, slot k1
     const int lane1 = 1 / K;
@@ -372,6 +374,17 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
     double *endV = rowAd + 2 * (lane == 63 ? (1 % K) * AQ + PADQ + 64 + 1 / K : (1 % K) * AQ + PADQ + laneRO + 1 + 1 / K);
     double *oneV = rowAd + 2 * ((2 % K) * AQ + PADQ + 64 + 2 / K);
     const double endC = (lane == 63) ? NN : Nn_RO;
+    // One masked block per read base stores all three: the owners of LO / RO and the owner of state 1 run the same four stores with
+    // their own addresses and constants (state 1's owner has no first pair to give: it goes to the unused pad slot NP+3, which lane 63
+    // reads under c = -inf).  LO's idle position takes the emission of a state that matches every column, like RO's own, so the
+    // value that goes with beta is the lane's ov[K-1] in all three.
+    int pubFlag = (isEnd || (foldLO && lane == lane1)) ? 1 : 0;
+    asm volatile("" : "+v"(pubFlag));               // one opaque per-lane flag: one compare per read base instead of the three conditions re-derived
+    double *pubA = isEnd ? endA : rowAd + 2 * ((3 % K) * AQ + PADQ + 64 + 3 / K);
+    double *pubV = isEnd ? endV : oneV;
+    const double pubC = isEnd ? endC : NN;
+    const unsigned mLast = (foldLO && lane == 63) ? 0xffffffffu : mOwn[K - 1];
+    static_assert(!FOLD || (K <= 2 && k1 == K - 1), "the folded publish block takes state 1 from its lane's last slot");
 
     const int64_t pair_base = P.win_pair_off[w] + (int64_t)(g - h0) * R;
     const int rs_base = P.read_seq_off[r0];
@@ -438,9 +451,6 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
             const int kk = i / (2 * PADQ), j = i - kk * (2 * PADQ);
             rowA[kk * AQ + (j < PADQ ? j : 64 + j)] = make_double2(NEG_INF, 0.0);
         }
-        if constexpr (foldLO) {          // constant halves of the end states' slots (the changing halves are stored per read base)
-            if (lane == lane1) oneV[1] = NN;
-        }
         STAMP(1);   // bMid + staging
         double a[K], in[K];           // current slice: "on base x" and "inserted at x"
         // ================= right -> middle: passMessageTwoInc for b = L-1..bMid+1 (:1576-1578, :1715-1773)
@@ -481,15 +491,15 @@ __global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT
                 double v[D + K], ov[D + K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    ov[k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
+                    const unsigned mk = (foldLO && k == K - 1) ? mLast : mOwn[k];
+                    ov[k] = ((mk >> col) & 1u) ? eq : uq;
                     v[k] = a[k];
                     rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[k]);
                 }
                 if constexpr (foldLO) {                            // what the end states' generic candidates read (after the owners' own slots)
                     // 8-byte stores (RO's two slots are ordinary positions whose owner has just stored its own pair there: both halves are
-                    // rewritten; LO's slot NP+2 is a pad, its constant half was stored when the read began)
-                    if (isEnd) { endA[0] = a[K - 1]; endA[1] = eq; endV[0] = eq + a[K - 1]; endV[1] = endC; }
-                    if (lane == lane1) oneV[0] = ov[k1] + a[k1];
+                    // rewritten)
+                    if (pubFlag) { pubA[0] = a[K - 1]; pubA[1] = ov[K - 1]; pubV[0] = ov[K - 1] + a[K - 1]; pubV[1] = pubC; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1098,7 +1108,7 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, u
 }
 #else
 // The product library instantiates K = 1..12 positions per lane x the D builds 6 / 11 / 12 x {LDS, HBM-scratch} back-pointers:
-// 72 kernels, plus the FOLD variants of the K = 1 and K = 2 LDS builds at D = 6.  The file is compiled once per D build (-DDD_INST_D=6|11|12, see the Makefile) so that they build in parallel;
+// 72 kernels, plus the FOLD variants: K = 1 and K = 2 LDS builds at D = 6, the K = 2 scratch build at D = 6, the K = 2 LDS build at D = 11.  The file is compiled once per D build (-DDD_INST_D=6|11|12, see the Makefile) so that they build in parallel;
 // the D = 6 unit also carries the dispatcher and the small kernels.
 template <int D, bool GBT>
 static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
@@ -1124,19 +1134,21 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
 #define DD_INST_D 0            // 0: every D build in this unit
 #endif
 hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
-hipError_t launch_hmm_d11(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d11(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 #if DD_INST_D == 0 || DD_INST_D == 6
 hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
     if (fold && !gbt && K == 1) return launch_one<1, 6, false, true>(A, g, waves, lds, st);
     if (fold && !gbt && K == 2) return launch_one<2, 6, false, true>(A, g, waves, lds, st);
+    if (fold && gbt && K == 2) return launch_one<2, 6, true, true>(A, g, waves, lds, st);
     return gbt ? launch_k<6, true>(K, A, g, waves, lds, st) : launch_k<6, false>(K, A, g, waves, lds, st);
 }
 #endif
 #if DD_INST_D == 0 || DD_INST_D == 11
-hipError_t launch_hmm_d11(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm_d11(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
+    if (fold && !gbt && K == 2) return launch_one<2, 11, false, true>(A, g, waves, lds, st);
     return gbt ? launch_k<11, true>(K, A, g, waves, lds, st) : launch_k<11, false>(K, A, g, waves, lds, st);
 }
 #endif
@@ -1152,7 +1164,7 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, u
 {
     switch (Dt) {
     case 6: return launch_hmm_d6(K, gbt, fold, A, dim3(grid), waves, lds, st);
-    case 11: return launch_hmm_d11(K, gbt, A, dim3(grid), waves, lds, st);
+    case 11: return launch_hmm_d11(K, gbt, fold, A, dim3(grid), waves, lds, st);
     case 12: return launch_hmm_d12(K, gbt, A, dim3(grid), waves, lds, st);
     default: return hipErrorInvalidValue;
     }

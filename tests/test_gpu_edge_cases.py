@@ -542,3 +542,18 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     K = (max(len(hap), len(alt)) + 2 + 63) // 64
     fits = 64 * K >= max(len(hap), len(alt)) + 3
     assert name_plain.endswith("false>") and name_folded.endswith("true>" if fits else "false>"), (name_folded, name_plain)
+    if K == 2:
+        # the two other builds that carry the fold: maxLengthDel = 10 (D build 11, LDS back-pointers) and reads long enough for the
+        # scratch build at D = 6
+        p10 = capi.params_cli_defaults(); p10.maxLengthDel = 10
+        pl = pack([Window(1000, [hap, alt], reads_from(hap, 14, 170, junk=0.1) + reads_from(hap, 4, 200, junk=0.0))])
+        for params, batch, tag in ((p10, pb, "11, false"), (p, pl, "6, true")):
+            got = run_host_api(lib, params, batch)
+            name = lib.dd_kernel_name().decode()
+            monkeypatch.setenv("DD_NO_FOLD", "1")
+            ref = run_host_api(lib, params, batch)
+            monkeypatch.delenv("DD_NO_FOLD")
+            w2 = _oracle.batch(params, batch, nthreads=8)
+            assert_same(got, w2, batch)
+            assert_same(ref, w2, batch)
+            assert ("<2, %s, " % tag) in name and name.endswith("true>" if fits else "false>"), name
