@@ -121,6 +121,7 @@ uint32_t bt_word_bytes(int K, int Dt)
 struct Plan {
     int K, Dt, waves, waves_per_cu;
     bool gbt;
+    bool two_waves = false;  // K = 3 / D = 6 scratch build: the variant compiled for 2 waves per SIMD (LDS keeps fewer than 12 waves on the CU anyway)
     size_t lds, scratch_bytes;
     unsigned grid_cap;       // 0 = one workgroup per item
 };
@@ -145,14 +146,32 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     }
     if (best[0] == 0 && best[1] == 0)
         return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length does not fit the LDS row buffers");
+    // K = 3 / D = 6 scratch: the 3-waves-per-SIMD build only where LDS lets 12 waves stay (reads up to ~250 bp); beyond, the build
+    // for 2 waves per SIMD (no spills) with the geometry that fills 8: 9 waves of the spilling build lost 9 % to it at 400-bp reads
+    pl.two_waves = false;
+    if (pl.K == 3 && pl.Dt <= 7 && best[1] > 0 && best[1] < 12) {
+        pl.two_waves = true;
+        best[1] = 0; bw[1] = 0; cap[1] = 8;
+        for (int wv = DD_WAVES; wv >= 1; wv--) {
+            ddk::KernelArgs tmp = A;
+            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, true, tmp);
+            if (l > 160u * 1024u) continue;
+            int total = (int)((160u * 1024u) / l) * wv;
+            if (total > 8) total = 8;
+            if (total > best[1]) { best[1] = total; bw[1] = wv; }
+        }
+    }
     // HBM scratch costs a coalesced row fetch per 8 traceback steps and (D=11) block-shared constants; the LDS tile
     // costs occupancy.  Measured over six shapes (tools/ab_point.py with DD_FORCE_GBT=0/1): the LDS build wins
     // whenever its tile still lets the CU hold as many waves as its registers allow, the scratch build wins
     // (5-80 %) once LDS caps it below that (tools/plan_check.py grid: at 10 of 12 waves the scratch build is already
     // 14 % ahead).
     // For K >= 3 the scratch build is also the register-lean one (block-shared constants) and wins at every
-    // shape measured (+26 ... +41 %).
-    pl.gbt = best[0] == 0 || (pl.K >= 3 && best[1] > 0) || best[0] < cap[0];
+    // shape measured (+26 ... +41 % in round 2; +10 ... +30 % on the round-3 grid) — except K = 3 at D = 6 with reads short
+    // enough (<= 90 bp) for the LDS tile to keep the 8 waves its registers allow: there the LDS build is 4-10 % ahead of the
+    // scratch build (profiles/r03/plan_check.jsonl, k3_lds_vs_scratch.jsonl), so that case follows the K <= 2 rule.
+    const bool lean_only = pl.K >= 3 && !(pl.K == 3 && pl.Dt <= 7);
+    pl.gbt = best[0] == 0 || (lean_only && best[1] > 0) || best[0] < cap[0];
     if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
         if (f[0] == '1' && best[1] > 0) pl.gbt = true;
         if (f[0] == '0' && best[0] > 0) pl.gbt = false;
@@ -282,6 +301,7 @@ static thread_local int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pe
 static thread_local char g_kernel_name[64] = "dd_hmm_kernel";
 static thread_local int g_last_direct = 0;     // output arrays the last host-pointer call on this thread let the kernels write in place
 static thread_local int g_last_fold = 0;       // the last main-model launch used the FOLD build (hmm_kernel.hip)
+static thread_local int g_last_occ = 0;        // ... the build variant compiled for that many waves per SIMD (0 = the build's usual occupancy)
 
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
@@ -295,7 +315,7 @@ const char *dd_last_error(void) { return g_err.c_str(); }
 const char *dd_kernel_name(void)
 {   // the template instance this host thread launched last, as rocprofv3 prints it (inside "void ddk::...(ddk::KernelArgs)")
     const int K = g_last_launch[0], D = g_last_launch[1];
-    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s, %s>", K, D % 100, D >= 100 ? "true" : "false", g_last_fold ? "true" : "false");
+    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s, %s, %d>", K, D % 100, D >= 100 ? "true" : "false", g_last_fold ? "true" : "false", g_last_occ);
     else if (K > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_faster_kernel");
     return g_kernel_name;
 }
@@ -912,7 +932,9 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     const bool fold_build = pl.gbt ? (K == 2 && Dt == 6) : ((K <= 2 && Dt == 6) || (K == 2 && Dt == 11));     // the builds measured to gain from it
     const bool fold = fold_build && 64 * K >= cls_hap + 3 && !getenv("DD_NO_FOLD");
     g_last_fold = fold ? 1 : 0;
-    HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, fold, A, (unsigned)grid, waves, lds, st));
+    g_last_occ = (pl.gbt && pl.two_waves) ? 2 : 0;
+    const int build = (fold ? DD_BUILD_FOLD : 0) | ((pl.gbt && pl.two_waves) ? DD_BUILD_TWO_WAVES : 0);
+    HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, build, A, (unsigned)grid, waves, lds, st));
     if (r->onHap && r->offHapHMQ && (!lc || lc->run_onhap)) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
 }

@@ -84,9 +84,12 @@ __device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
-/* fold: the build whose right->middle pass carries the LO / RO end states in the generic candidate code (K <= 2, D build 6, LDS
- * back-pointers; every haplotype of the launch must leave position 64 K - 1 idle: 64 K >= Hs + 3) */
-hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
+/* build: which variant of the (K, D, back-pointer) build — DD_BUILD_FOLD: the right->middle pass carries the LO / RO end states in the
+ * generic candidate code (K <= 2; every haplotype of the launch must leave position 64 K - 1 idle: 64 K >= Hs + 3);
+ * DD_BUILD_TWO_WAVES: the K = 3 / D = 6 scratch build compiled for 2 waves per SIMD instead of 3 */
+#define DD_BUILD_FOLD 1
+#define DD_BUILD_TWO_WAVES 2
+hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */
 

@@ -182,8 +182,11 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // a few tens of MB for the whole chip, so it lives in L2 / Infinity Cache.
 // FOLD: the right->middle pass runs its LO / RO end states inside the generic candidate code (see foldRO in the body); built
 // for the LDS builds with K <= 2, D = 6 only (the other builds lose more to the extra stores than the blocks cost them).
-template <int K, int D, bool GBT, bool FOLD = false>
-__global__ void __launch_bounds__(DD_WAVES * 64, DD_MIN_WAVES_PER_SIMD(K, D, GBT)) dd_hmm_kernel(const KernelArgs P)
+// OCC: waves per SIMD the register allocator is held to when it is not the rule above (0 = the rule).  One build uses it: K = 3 at D = 6
+// with scratch back-pointers also exists at 2 waves per SIMD, for reads so long (> ~250 bp) that LDS keeps fewer than 12 waves on
+// the CU anyway — there the 3-wave build's spills cost 9 % and buy nothing (profiles/r03/plan_check.jsonl).
+template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0>
+__global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SIMD(K, D, GBT)) dd_hmm_kernel(const KernelArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1076,7 +1079,7 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
 }
 #endif
 
-template <int K, int D, bool GBT, bool FOLD = false>
+template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
     // The cap on dynamic LDS is a property of the function, not of a launch: it is raised ONCE per template instance (and
@@ -1088,19 +1091,20 @@ static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t l
     if (e != hipSuccess) return e;
     const unsigned bit = 1u << (dev & 31);
     if (!(raised.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT, FOLD>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT, FOLD, OCC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_release);
     }
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT, FOLD>), grid, dim3(waves * 64), lds, st, A);
+    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT, FOLD, OCC>), grid, dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }
 
 #ifdef DD_ONLY_K   // diagnostic builds: a single (K, D) compiles in seconds
-hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
+    const bool fold = (build & DD_BUILD_FOLD) != 0;
     if (K != DD_ONLY_K || Dt != DD_ONLY_D) return hipErrorInvalidValue;
     if (fold && !gbt) return launch_one<DD_ONLY_K, DD_ONLY_D, false, true>(A, dim3(grid), waves, lds, st);
     return gbt ? launch_one<DD_ONLY_K, DD_ONLY_D, true>(A, dim3(grid), waves, lds, st)
@@ -1133,12 +1137,14 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
 #ifndef DD_INST_D
 #define DD_INST_D 0            // 0: every D build in this unit
 #endif
-hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
-hipError_t launch_hmm_d11(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d11(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 #if DD_INST_D == 0 || DD_INST_D == 6
-hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
+    const bool fold = (build & DD_BUILD_FOLD) != 0;
+    if (gbt && K == 3 && (build & DD_BUILD_TWO_WAVES)) return launch_one<3, 6, true, false, 2>(A, g, waves, lds, st);
     if (fold && !gbt && K == 1) return launch_one<1, 6, false, true>(A, g, waves, lds, st);
     if (fold && !gbt && K == 2) return launch_one<2, 6, false, true>(A, g, waves, lds, st);
     if (fold && gbt && K == 2) return launch_one<2, 6, true, true>(A, g, waves, lds, st);
@@ -1146,8 +1152,9 @@ hipError_t launch_hmm_d6(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g
 }
 #endif
 #if DD_INST_D == 0 || DD_INST_D == 11
-hipError_t launch_hmm_d11(int K, bool gbt, bool fold, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm_d11(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
+    const bool fold = (build & DD_BUILD_FOLD) != 0;
     if (fold && !gbt && K == 2) return launch_one<2, 11, false, true>(A, g, waves, lds, st);
     return gbt ? launch_k<11, true>(K, A, g, waves, lds, st) : launch_k<11, false>(K, A, g, waves, lds, st);
 }
@@ -1160,11 +1167,11 @@ hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int wave
 #endif
 
 #ifdef DD_INST_COMMON
-hipError_t launch_hmm(int K, int Dt, bool gbt, bool fold, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
     switch (Dt) {
-    case 6: return launch_hmm_d6(K, gbt, fold, A, dim3(grid), waves, lds, st);
-    case 11: return launch_hmm_d11(K, gbt, fold, A, dim3(grid), waves, lds, st);
+    case 6: return launch_hmm_d6(K, gbt, build, A, dim3(grid), waves, lds, st);
+    case 11: return launch_hmm_d11(K, gbt, build, A, dim3(grid), waves, lds, st);
     case 12: return launch_hmm_d12(K, gbt, A, dim3(grid), waves, lds, st);
     default: return hipErrorInvalidValue;
     }

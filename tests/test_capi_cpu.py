@@ -176,9 +176,12 @@ def test_launch_plan_rules(lib):
         [1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 11, 12, 12]
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
-    # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 3
+    # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6
     assert [plan(L=l)["hbm"] for l in (36, 100, 110, 120, 150, 250, 1000)] == [0, 0, 0, 1, 1, 1, 1]
     assert plan(hap=170)["hbm"] == 1 and plan(hap=170)["scratch_kib"] > 0 and plan()["scratch_kib"] == 0
+    # K = 3 at D = 6: the LDS tile for reads up to 90 bp (it then holds the 8 waves the registers allow), scratch beyond and for maxLengthDel >= 6 / K >= 4
+    assert [plan(hap=170, L=l)["hbm"] for l in (36, 76, 90, 100, 150)] == [0, 0, 0, 1, 1]
+    assert plan(hap=170, L=76, mld=10)["hbm"] == 1 and plan(hap=200, L=76)["hbm"] == 1
     assert plan()["waves"] == 4 and plan()["waves_cu"] == 12 and plan()["lds"] <= 160 * 1024
     # workgroup size follows how well the windows' reads fill the waves
     assert [plan(reads=r)["waves"] for r in (1, 2, 3, 5, 10, 20, 200)] == [1, 2, 3, 1, 2, 4, 4]

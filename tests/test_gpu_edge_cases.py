@@ -516,6 +516,19 @@ def test_multi_device_block_of_windows_without_haplotypes(lib):
     assert none["onHap"][:pe.n_reads].max() == 0
 
 
+def test_k3_scratch_build_variants(lib):
+    """K = 3 at D = 6: reads up to 90 bp run the LDS build, longer ones the scratch build compiled for 3 waves per SIMD, and reads so long
+    that LDS keeps fewer than 12 waves on the CU (> ~250 bp) its 2-waves-per-SIMD variant — all three equal the oracle."""
+    p = capi.params_cli_defaults()
+    hap = rnd(150)
+    alt = hap[:70] + hap[73:]
+    for L, want_name in ((76, "dd_hmm_kernel<3, 6, false, false, 0>"), (160, "dd_hmm_kernel<3, 6, true, false, 0>"), (330, "dd_hmm_kernel<3, 6, true, false, 2>")):
+        pb = pack([Window(1000, [hap, alt], reads_from(hap, 14, L, junk=0.1) + reads_from(alt, 6, L, junk=0.0))])
+        got = run_host_api(lib, p, pb)
+        assert lib.dd_kernel_name().decode() == want_name, (L, lib.dd_kernel_name().decode())
+        assert_same(got, _oracle.batch(p, pb, nthreads=8), pb)
+
+
 @pytest.mark.parametrize("hs", [30, 59, 60, 61, 62, 100, 118, 120, 121, 123, 124, 125, 126])
 def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     """Round 3: for K <= 2 at D = 6 the right->middle pass carries the LO / RO end states in the generic candidate code
@@ -541,7 +554,7 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     assert_same(plain, want, pb)
     K = (max(len(hap), len(alt)) + 2 + 63) // 64
     fits = 64 * K >= max(len(hap), len(alt)) + 3
-    assert name_plain.endswith("false>") and name_folded.endswith("true>" if fits else "false>"), (name_folded, name_plain)
+    assert name_plain.endswith("false, 0>") and name_folded.endswith("true, 0>" if fits else "false, 0>"), (name_folded, name_plain)
     if K == 2:
         # the two other builds that carry the fold: maxLengthDel = 10 (D build 11, LDS back-pointers) and reads long enough for the
         # scratch build at D = 6
@@ -556,4 +569,4 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
             w2 = _oracle.batch(params, batch, nthreads=8)
             assert_same(got, w2, batch)
             assert_same(ref, w2, batch)
-            assert ("<2, %s, " % tag) in name and name.endswith("true>" if fits else "false>"), name
+            assert ("<2, %s, " % tag) in name and name.endswith("true, 0>" if fits else "false, 0>"), name
