@@ -509,6 +509,18 @@ void LikelihoodEngine::warmUp(size_t pairs)
     // per pair: ~25 input bytes (a read of 100 bases is shared by its window's haplotypes) and ~270 result bytes if everything is staged
     const size_t bytes = pairs * 300 + (size_t(32) << 20);
     if (dd_reserve_cache(device_, bytes, bytes <= (size_t(64) << 20) ? bytes : 0) != DD_SUCCESS) throw std::string("dd_reserve_cache: ") + dd_last_error();
+    // two result blocks with their per-pair arrays at that size, made now (page-locking 90 MB takes 40-100 ms): a pipelined caller
+    // would otherwise grow its blocks step by step under its first batches.  The per-base and per-variant arrays follow the data.
+    const size_t np = pairs + 1;
+    while (spare_.size() < 2) {
+        std::shared_ptr<BatchBlock> blk = std::make_shared<BatchBlock>();
+        BatchBlock &B = *blk;
+        B.ll.reserve(np); B.llOn.reserve(np); B.llOff.reserve(np); B.mLogBQ.reserve(np);
+        B.offHap.reserve(np); B.offHapHMQ.reserve(np); B.status.reserve(np);
+        B.numIndels.reserve(np); B.numMismatch.reserve(np); B.nBQT.reserve(np); B.nmmBQT.reserve(np);
+        B.nMMLeft.reserve(np); B.nMMRight.reserve(np); B.firstBase.reserve(np); B.lastBase.reserve(np);
+        spare_.push_back(blk);
+    }
 }
 
 void LikelihoodEngine::computeLikelihoodsFasterBatch(std::vector<WindowJob> &jobs) { runBatch(jobs, true); }
