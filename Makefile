@@ -11,7 +11,7 @@ bench:                     # needs an MI355X
 window-loop:               # needs an MI355X: synthetic BAM -> .glf.txt -> VCF with the calls checked against the simulated variants
 	python tools/n2_pipeline_bench.py --windows 60000 --vcf
 sanitize: build            # ASan + UBSan over the CPU-side code, TSan over the window loop's threads; no GPU
-	bash tools/sanitize_cpu.sh
+	bash tests/sanitize_cpu.sh
 clean:
 	$(MAKE) -C dindel_tgi_amd/csrc clean
 	$(MAKE) -C dindel_tgi_amd/host clean

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long randomised GPU-vs-oracle parity campaign (both models), beyond what the test-suite budget allows.
-  python tools/fuzz_campaign.py [--seconds 300] [--seed0 0]
+  python tests/fuzz_campaign.py [--seconds 300] [--seed0 0]
 Every round draws a shape class, parameters and adversarial windows (tests/test_gpu_fuzz.make_windows plus
 synth.generate mixes), runs the C ABI and the oracle (16 threads) and requires bit-equality.  Prints one line per
 round; exits non-zero at the first mismatch after dumping the seed."""

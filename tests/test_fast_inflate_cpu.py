@@ -1,7 +1,7 @@
 """host/fast_inflate.cpp — the raw-DEFLATE decoder the BGZF reader tries before zlib — against zlib itself: streams made by zlib at every level
 and strategy (stored, fixed and dynamic Huffman blocks, long and short matches, overlapping copies, long codes) decode to the same bytes;
 damaged streams are declined or give bytes that the block's CRC would reject, and never touch memory outside the output buffer (the test runs
-under ASan in tools/sanitize_cpu.sh)."""
+under ASan in tests/sanitize_cpu.sh)."""
 import ctypes as C
 import zlib
 

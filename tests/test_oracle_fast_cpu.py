@@ -1,7 +1,7 @@
 """CPU-only checks of the --faster restatement (oracle/dd_oracle.c: ddo_pair_fast / ddo_batch_fast) on adversarial
 windows: the batch driver against the per-pair function, plus properties of ObservationModelS that hold for any input
 (Faster.cpp:491/:529 make offHap / offHapHMQ always false; hpos values stay inside the haplotype; a read identical to a
-haplotype segment scores higher on that haplotype than on a shuffled one).  Runs under ASan via tools/sanitize_cpu.sh."""
+haplotype segment scores higher on that haplotype than on a shuffled one).  Runs under ASan via tests/sanitize_cpu.sh."""
 import numpy as np
 
 from dindel_tgi_amd import capi
