@@ -696,13 +696,19 @@ enum Model { MODEL_FBMAXERR = 0 /* ObservationModelFBMaxErr, computeLikelihoods 
 // the --faster one): a workgroup's waves take the units round-robin, so with few units some waves idle in the last round
 // while the workgroup's LDS stays allocated.  Keep `maxw` unless a smaller workgroup uses its waves > 10 % better
 // (tools/coverage_sweep.py: 2 reads per window ran at half the rate with 4-wave workgroups).
-static int waves_for_reads(int64_t units, int maxw)
+// per_cu: waves the build keeps on a CU — workgroups of w waves leave per_cu % w of them unused (three-wave workgroups of a build
+// held to 8 waves: 6 resident; the --faster kernel ran 10-read windows at 3.7e11 instead of 4.6e11 that way)
+static int waves_for_reads(int64_t units, int maxw, int per_cu)
 {
     if (units < 1) units = 1;
+    if (per_cu < maxw) per_cu = maxw;
+    auto use = [&](int w) {
+        return (double)units / (double)(((units + w - 1) / w) * w) * (double)((per_cu / w) * w) / (double)per_cu;
+    };
     int best = maxw;
-    double bestu = (double)units / (double)(((units + maxw - 1) / maxw) * maxw);
+    double bestu = use(maxw);
     for (int w = maxw - 1; w >= 1; w--) {
-        const double u = (double)units / (double)(((units + w - 1) / w) * w);
+        const double u = use(w);
         if (u > bestu * 1.10) { best = w; bestu = u; }
     }
     return best;
@@ -810,7 +816,7 @@ static int launch_fast(const dd_params *p, const dd_device_batch *b, ddk::Kernel
     if (const char *e = getenv("DD_FAST_TARGET_BLOCKS")) { const long v = atol(e); if (v >= 1) target_blocks = v; }   // A/B only
     int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
     {   // thin windows: no more wavefronts per workgroup than the windows have groups of `groups` reads
-        const int w2 = waves_for_reads((avg_reads + groups - 1) / groups, waves);
+        const int w2 = waves_for_reads((avg_reads + groups - 1) / groups, waves, 8);
         if (w2 != waves) {
             waves = w2;
             lds = (size_t)A.lds_shared_bytes + (size_t)waves * (groups < 4 ? groups + 1 : 4) * A.lds_wave_bytes;
@@ -883,7 +889,7 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     // reads (tools/coverage_sweep.py: 2 reads per window ran at half the rate with idle waves in every workgroup)
     const int64_t avg_reads_w = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
     {
-        const int w2 = waves_for_reads(avg_reads_w, waves);
+        const int w2 = waves_for_reads(avg_reads_w, waves, pl.waves_per_cu);
         if (w2 != waves) {
             waves = w2;
             lds = lds_layout(K, Dt, cls_read, b->n_qual, waves, pl.gbt, A);
@@ -950,7 +956,7 @@ int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qu
     ddk::KernelArgs A;
     memset(&A, 0, sizeof(A));
     if ((rc = make_plan(p, max_hap_len, max_read_len, n_qual, pl, A))) return rc;
-    const int waves = waves_for_reads(avg_reads, pl.waves);
+    const int waves = waves_for_reads(avg_reads, pl.waves, pl.waves_per_cu);
     out[0] = pl.K; out[1] = pl.Dt; out[2] = pl.gbt ? 1 : 0; out[3] = waves;
     out[5] = (int32_t)lds_layout(pl.K, pl.Dt, max_read_len, n_qual, waves, pl.gbt, A);
     out[4] = (int32_t)pick_split(n_haps, avg_reads, waves, 4096,
