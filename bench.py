@@ -192,6 +192,53 @@ def window_loop_leg(faster, windows=100000):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def ragged_leg(params, device, windows=2400, steps=3):
+    """The shapes real windows have (synth.generate_ragged: 121-bp-and-up reference haplotypes as python/makeWindows.py:72-75 cuts them, 2-12
+    candidate haplotypes of different lengths per window, 20-400 reads of 36 / 76 / 100 / 150 bp, mixed qualities), resident in HBM, one
+    dd_launch_device per step = one launch per (haplotype-length class, read-length class).  Beside the headline figure, never part of it."""
+    try:
+        pb = synth.generate_ragged(windows)
+        dev = DeviceBatch(pb, params, device)
+        dev.launch()
+        torch.cuda.synchronize(device)
+        ev = []
+        for _ in range(steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dev.launch(); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize(device)
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        log = capi.launch_log()
+        st = dev.out["status"][:pb.n_pairs]
+        assert int((st != 0).sum().item()) == 0, "non-OK pair status in the ragged batch"
+        # lane utilisation of a launch: states its haplotypes have / positions their wavefronts sweep
+        hl = np.diff(pb.a["hap_seq_off"]).astype(np.int64)
+        rl = np.diff(pb.a["read_seq_off"]).astype(np.int64)
+        hw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_hap_off"]))
+        rw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_read_off"]))
+        launches = []
+        for rec in log:
+            lo_h = max([0] + [q["max_hap"] for q in log if q["max_hap"] < rec["max_hap"]])
+            hsel = (hl > lo_h) & (hl <= rec["max_hap"])
+            rsel = (rl >= rec["min_read"]) & (rl <= rec["max_read"])
+            rsum = np.bincount(rw[rsel], weights=rl[rsel], minlength=pb.n_windows)
+            cells = float((hl[hsel] * rsum[hw[hsel]]).sum())
+            pos = 64 * rec["K"] // rec["pairs_per_wave"]
+            launches.append({"K": rec["K"], "pairs_per_wave": rec["pairs_per_wave"], "D": rec["D"], "bt": "hbm" if rec["gbt"] else "lds", "fold": bool(rec["fold"]),
+                             "haplotypes": int(hsel.sum()), "hap_len": [int(hl[hsel].min()), int(hl[hsel].max())] if hsel.any() else None,
+                             "read_len": [rec["min_read"], rec["max_read"]], "share_of_cells": cells / pb.cells,
+                             "lane_utilisation": float((hl[hsel] + 2).mean() / pos) if hsel.any() else None,
+                             "ms": rec["us"] / 1e3 if rec["us"] >= 0 else None})
+        return {"what": "%d windows as the reference's pipeline shapes them (synth.generate_ragged: haplotypes %d-%d bp, %d-%d per window, reads %d-%d bp, "
+                        "%d-%d per window; mixed qualities), HBM-resident, one dd_launch_device per step" %
+                        (pb.n_windows, int(hl.min()), int(hl.max()), int(np.diff(pb.a["win_hap_off"]).min()), int(np.diff(pb.a["win_hap_off"]).max()),
+                         int(rl.min()), int(rl.max()), int(np.diff(pb.a["win_read_off"]).min()), int(np.diff(pb.a["win_read_off"]).max())),
+                "cells_per_s": pb.cells / (ms * 1e-3), "windows_per_s": pb.n_windows / (ms * 1e-3), "pairs": pb.n_pairs, "cells": pb.cells,
+                "ms_per_step": ms, "steps": steps, "launches": launches}
+    except Exception as e:                          # noqa: BLE001  (the headline figures do not depend on this leg)
+        return {"error": repr(e)[:400]}
+
+
 def in_process_leg(pb, params, world, devices, dev, args):
     """N devices driven from ONE process: dd_compute_likelihoods_multi on a batch of N x --windows windows held in host memory (contiguous
     window blocks balanced by cells, one host thread + arena + streams per device, no collective) — the form that matches the reference's
@@ -276,6 +323,7 @@ def main():
     ap.add_argument("--max-length-del", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-window-loop", action="store_true", help="skip the BAM -> .glf.txt window-loop leg (N=1)")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the real-shaped (ragged) batch leg (N=1)")
     ap.add_argument("--host-api", action="store_true", help="(kept for old command lines: the host-API legs now run by default at N=1)")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the legs beside the headline figure: at N=1 the host API (copies included) and the C++ adapter end to end, "
@@ -436,6 +484,7 @@ def main():
             total_windows = args.windows * world * args.steps
         value = total_cells / elapsed
         bpp = algorithmic_bytes_per_pair(args.read_len, args.hap_len, args.reads)
+        default_shape = (args.windows, args.haps, args.reads, args.read_len, args.hap_len, args.max_length_del) == (10000, 8, 200, 100, 120, 5)
         achieved = bpp * n_pairs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "read-haplotype HMM cells/s", "value": value, "unit": "cells/s",
@@ -448,7 +497,7 @@ def main():
                                     else "%d windows/GPU " % args.windows) +
                                    "x %d haplotypes x %d reads, %d bp reads (Q30), %d bp haplotypes, maxLengthDel=%d%s"
                                    % (args.haps, args.reads, args.read_len, args.hap_len, args.max_length_del,
-                                      "" if strong else " (BASELINE.json configs[1])"),
+                                      " (BASELINE.json configs[1])" if default_shape and not strong else ""),
                        "windows_per_gpu": windows_this_rank, "pairs_per_gpu": step_pairs, "cells_per_gpu": step_cells,
                        "sub_batches_per_gpu": [[d.pb.n_windows, k] for d, k in plan],
                        "sharding": "contiguous window blocks per rank; gather of ll+flags to rank 0" if world > 1 else "single GPU"},
@@ -505,6 +554,8 @@ def main():
                 "frac_of_kernel_only": (args.windows / lazy["seconds"]) / (total_windows / elapsed)}
             if not args.no_window_loop:
                 out["window_loop"] = window_loop_leg(args.faster)
+        if world == 1 and not strong and not args.no_ragged and not args.faster:
+            out["ragged"] = ragged_leg(params, device)
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would idle in the collective teardown)
             out["cpu_baseline"] = cpu_baseline(pb, params, faster=args.faster)
         if args.faster:

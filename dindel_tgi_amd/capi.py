@@ -21,7 +21,7 @@ c_f64p = C.POINTER(C.c_double)
 DD_TABLE_DOUBLES = 32 + 4 * 256 + 4 * 256 + 2 * 64 + 2 * 256 + 2 * 256 + 64
 DD_READ_UNMAPPED, DD_READ_PAIRED, DD_READ_MATE_UNMAPPED, DD_READ_MATE_REVERSE, DD_READ_MATE_SAME_TID = 1, 2, 4, 8, 16
 
-ABI_VERSION = 11           # DD_ABI_VERSION of include/dindel_hmm.h
+ABI_VERSION = 12           # DD_ABI_VERSION of include/dindel_hmm.h
 DD_HPOS_INS, DD_HPOS_LO, DD_HPOS_RO, DD_HPOS_INS_KEY0 = -1, -3, -4, -16
 
 DD_SUCCESS, DD_ERR_NO_DEVICE, DD_ERR_INVALID, DD_ERR_UNSUPPORTED, DD_ERR_HIP = 0, -1, -2, -3, -4
@@ -101,8 +101,14 @@ class dd_device_batch(C.Structure):
                 ("hap_class_list", C.c_void_p), ("classes", C.c_void_p), ("win_skip", C.c_void_p)]
 
 
+# haplotype-length classes of a ragged batch, one per lane tiling (capi.cpp kHapClasses): longest haplotype, pairs per wavefront, positions per lane
+HAP_CLASSES = [(30, 2, 1), (62, 2, 2), (94, 2, 3), (126, 1, 2), (158, 2, 5), (190, 1, 3), (222, 2, 7), (254, 1, 4), (318, 1, 5), (382, 1, 6),
+               (446, 1, 7), (510, 1, 8), (574, 1, 9), (638, 1, 10), (702, 1, 11), (766, 1, 12)]
+HAP_CLASS_BOUNDS = [c[0] for c in HAP_CLASSES]
+
+
 class dd_length_classes(C.Structure):
-    _fields_ = [("hap_class_off", C.c_int32 * 13), ("hap_class_max", C.c_int32 * 12), ("n_read_classes", C.c_int32),
+    _fields_ = [("hap_class_off", C.c_int32 * 17), ("hap_class_max", C.c_int32 * 16), ("n_read_classes", C.c_int32),
                 ("read_class_lo", C.c_int32 * 2), ("read_class_max", C.c_int32 * 2)]
 
 
@@ -113,7 +119,7 @@ class dd_device_result(C.Structure):
 
 EXPORTS = ["dd_params_struct_defaults", "dd_params_cli_defaults", "dd_batch_sizes", "dd_batch_offsets", "dd_screen_windows",
            "dd_compute_likelihoods", "dd_compute_likelihoods_faster", "dd_compute_likelihoods_multi", "dd_compute_likelihoods_faster_multi", "dd_partition_windows", "dd_launch_device_faster", "dd_release_cache", "dd_reserve_cache", "dd_host_alloc", "dd_host_free", "dd_build_tables", "dd_build_symbol_lut", "dd_build_library_tables", "dd_build_length_classes", "dd_plan_info", "dd_build_index", "dd_workspace_bytes",
-           "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_last_direct_outputs", "dd_pair_sum_offsets", "dd_pair_sums_device",
+           "dd_launch_device", "dd_kernel_name", "dd_last_launch", "dd_launch_log", "dd_last_direct_outputs", "dd_pair_sum_offsets", "dd_pair_sums_device",
            "dd_pair_sums", "dd_map_pairs_device", "dd_map_pairs", "dd_last_error", "dd_abi_version", "dd_device_count"]
 
 _lib = None
@@ -157,7 +163,7 @@ def load():
     lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
     lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_u8p, c_i32p, C.POINTER(dd_length_classes)]
     lib.dd_screen_windows.argtypes = [C.POINTER(dd_batch), c_u8p, C.POINTER(C.c_int32 * 2)]
-    lib.dd_plan_info.argtypes = [C.POINTER(dd_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]
+    lib.dd_plan_info.argtypes = [C.POINTER(dd_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32 * 10)]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]
     lib.dd_workspace_bytes.argtypes = [C.POINTER(dd_params), C.POINTER(dd_device_batch)]
     lib.dd_workspace_bytes.restype = C.c_size_t
@@ -170,6 +176,7 @@ def load():
     lib.dd_map_pairs.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p, C.POINTER(C.c_uint8), c_i32p, c_f64p, c_f64p, c_i32p, c_f64p, C.c_int]
     lib.dd_last_launch.argtypes = [C.POINTER(C.c_int32 * 8)]
     lib.dd_last_launch.restype = None
+    lib.dd_launch_log.argtypes = [c_i32p, C.c_int]
     lib.dd_last_direct_outputs.argtypes = []
     lib.dd_last_direct_outputs.restype = C.c_int
     lib.dd_kernel_name.restype = C.c_char_p
@@ -185,6 +192,18 @@ def last_launch():
     out = (C.c_int32 * 8)()
     load().dd_last_launch(C.byref(out))
     return dict(zip(["K", "D", "waves", "lds_block", "grid", "split", "lds_wave", "lds_shared"], list(out)))
+
+
+LAUNCH_LOG_FIELDS = ["K", "pairs_per_wave", "D", "gbt", "fold", "waves", "lds_block", "grid", "split", "n_haps", "max_hap", "min_read", "max_read",
+                     "waves_per_cu", "occ", "us"]
+
+
+def launch_log():
+    """Every main-model launch of the last dd_launch_device / dd_compute_likelihoods call of this thread (dd_launch_log)."""
+    import numpy as np
+    buf = np.zeros((64, len(LAUNCH_LOG_FIELDS)), np.int32)
+    n = load().dd_launch_log(buf.ctypes.data_as(c_i32p), 64)
+    return [dict(zip(LAUNCH_LOG_FIELDS, [int(v) for v in buf[i]])) for i in range(min(n, 64))]
 
 
 def last_error():

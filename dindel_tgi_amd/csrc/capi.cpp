@@ -47,13 +47,30 @@ double hp_error(int hpLen)
     return pbe;
 }
 
-int pick_K(int max_hap_len)
+// Lane tilings, by haplotype length.  numS = Hs + 2 states go over the 64 lanes of a wavefront, K positions per lane (every K = 1..12 is
+// instantiated, so no shape pays for more than 63 positions it does not have) — or, round 4, over the 32 lanes of HALF a wavefront, two
+// pairs side by side (G = 2), where 32 K is the tighter fit: 127..158 bp run as K = 5 halves (2.5 lane-positions per pair instead of 3),
+// 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves (3.5 instead of 4), and <= 62 bp as K = 2 / 1 halves (the same
+// positions as K = 1 on a whole wavefront, but a lane's second position comes from its own registers instead of the LDS exchange).
+struct HapClassDef { int bound, G, K; };     // haplotypes up to `bound` bp: G pairs per wavefront, K positions per lane
+const HapClassDef kHapClasses[DD_N_HAP_CLASSES] = {
+    {30, 2, 1}, {62, 2, 2}, {94, 2, 3}, {126, 1, 2}, {158, 2, 5}, {190, 1, 3}, {222, 2, 7}, {254, 1, 4},
+    {318, 1, 5}, {382, 1, 6}, {446, 1, 7}, {510, 1, 8}, {574, 1, 9}, {638, 1, 10}, {702, 1, 11}, {DD_MAX_HAP_LEN, 1, 12}};
+bool half_wave_off() { return getenv("DD_NO_HALF") != nullptr; }   // A/B and tests: whole-wavefront tilings only
+int hap_class_of(int hap_len)
 {
-    // numS = Hs + 2 states over 64 lanes: every K = 1..12 is instantiated, so no shape pays for positions it does not have
-    // (round 1 had {1,2,3,4,6,8,12}: a 383-bp haplotype ran on 512 positions instead of 448)
-    for (int k = 1; k <= 12; k++)
-        if (64 * k >= max_hap_len + 2) return k;
+    for (int c = 0; c < DD_N_HAP_CLASSES; c++)
+        if (hap_len <= kHapClasses[c].bound) return c;
     return -1;
+}
+// tiling for a launch whose longest haplotype is max_hap_len: false if it is too long
+bool pick_tiling(int max_hap_len, int &G, int &K)
+{
+    const int c = hap_class_of(max_hap_len);
+    if (c < 0) return false;
+    G = kHapClasses[c].G; K = kHapClasses[c].K;
+    if (G > 1 && half_wave_off()) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
+    return true;
 }
 
 int pick_Dt(int D)
@@ -68,9 +85,10 @@ int pick_Dt(int D)
 uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
 
 // LDS carve-up for (K, Dt, Lmax); returns total dynamic LDS bytes per workgroup
-size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk::KernelArgs &A)
+size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int G, ddk::KernelArgs &A)
 {
-    const uint32_t NP = 64u * K;
+    const uint32_t W = 64u / (uint32_t)G;        // lanes per pair
+    const uint32_t NP = W * K;
     uint32_t o = 0;
     o = up16(NP + 16);
     A.lds_off_L = o;  o += 256;                  // byte -> symbol id table
@@ -80,17 +98,21 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
     A.n_qual = n_qual;
     A.lds_off_C = o;  A.lds_off_Y = o;
     if (gbt && (Dt > 7 || K >= 3)) {             // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
-        o += up16((uint32_t)K * Dt * 64u * 8u);
+        o += up16((uint32_t)K * Dt * W * 8u);
         A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
     }
+    A.lds_off_S = o;
+    if (G > 1) o += up16(DD_HALF_CHUNK * 6u);    // half-wave builds: sort keys (u32) + order (u16) of a chunk of the window's reads
     A.lds_shared_bytes = o;
     uint32_t wv = 0;
-    A.lds_off_A = wv;   wv += up16((uint32_t)K * (64u + 2u * (uint32_t)((Dt + K - 1) / K)) * 16u);   // K arrays of {value, emission} + pads
+    A.lds_off_A = wv;   wv += up16((uint32_t)K * (W + 2u * (uint32_t)((Dt + K - 1) / K)) * 16u);   // K arrays of {value, emission} + pads
     A.lds_off_I = wv;   wv += up16((NP + 2) * 8);
     A.lds_off_rdE = wv; wv += up16(Lmax * 16);
     A.lds_off_rdC = wv; wv += up16(Lmax);
     A.lds_off_rdQ = wv; wv += up16(Lmax);
     A.lds_off_ms = wv;  wv += up16(Lmax * 2);
+    A.lds_group_bytes = wv;                      // the rows above exist once per pair of the wavefront; the back-pointer tile is the wavefront's
+    wv *= (uint32_t)G;
     {   // packed back-pointers: one word of K*(CB+1) bits per lane per read base (BtPack in hmm_kernel.hip)
         const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
         const uint32_t bytes = bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
@@ -102,11 +124,14 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, ddk:
 }
 
 // waves per CU the register file allows for each K (kernel-resource-usage of the shipped builds)
-int reg_limited_waves_per_cu(int K, int Dt, bool gbt)
+int reg_limited_waves_per_cu(int K, int Dt, bool gbt, int G = 1)
 {
+    (void)G;
+    if (const char *e = getenv("DD_REG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) return v; }   // A/B builds with another occupancy
     if (K <= 2) return (Dt <= 7 || gbt) ? 12 : 8;
     if (K == 3) return (gbt && Dt <= 7) ? 12 : ((gbt || Dt <= 7) ? 8 : 4);      // round 3: the D = 6 scratch build is held to 168 VGPRs (3 waves/SIMD)
     if (K == 4) return gbt ? 8 : 4;
+    if (K == 5 || G == 2) return gbt ? 8 : 4;    // round 4: the K = 5 scratch build held to 2 waves per SIMD gains 34 % over 1 (profiles/r04/occupancy_ab.txt)
     return 4;
 }
 
@@ -120,6 +145,7 @@ uint32_t bt_word_bytes(int K, int Dt)
 // the HBM-scratch build (GBT) with a persistent grid (one scratch tile per resident wave).
 struct Plan {
     int K, Dt, waves, waves_per_cu;
+    int G = 1;               // pairs per wavefront (2: the half-wave builds)
     bool gbt;
     bool two_waves = false;  // K = 3 / D = 6 scratch build: the variant compiled for 2 waves per SIMD (LDS keeps fewer than 12 waves on the CU anyway)
     size_t lds, scratch_bytes;
@@ -128,16 +154,15 @@ struct Plan {
 
 int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, Plan &pl, ddk::KernelArgs &A)
 {
-    pl.K = pick_K(max_hap_len);
     pl.Dt = pick_Dt(p->maxLengthDel + 1);
-    if (pl.K < 0) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
+    if (!pick_tiling(max_hap_len, pl.G, pl.K)) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
     int best[2] = {0, 0}, bw[2] = {0, 0}, cap[2] = {0, 0};
     for (int gbt = 0; gbt < 2; gbt++) {
-        const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0);
+        const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0, pl.G);
         cap[gbt] = reg_cap;
         for (int wv = DD_WAVES; wv >= 1; wv--) {
             ddk::KernelArgs tmp = A;
-            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, gbt != 0, tmp);
+            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, gbt != 0, pl.G, tmp);
             if (l > 160u * 1024u) continue;
             int total = (int)((160u * 1024u) / l) * wv;
             if (total > reg_cap) total = reg_cap;
@@ -149,12 +174,12 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     // K = 3 / D = 6 scratch: the 3-waves-per-SIMD build only where LDS lets 12 waves stay (reads up to ~250 bp); beyond, the build
     // for 2 waves per SIMD (no spills) with the geometry that fills 8: 9 waves of the spilling build lost 9 % to it at 400-bp reads
     pl.two_waves = false;
-    if (pl.K == 3 && pl.Dt <= 7 && best[1] > 0 && best[1] < 12) {
+    if (pl.G == 1 && pl.K == 3 && pl.Dt <= 7 && best[1] > 0 && best[1] < 12) {
         pl.two_waves = true;
         best[1] = 0; bw[1] = 0; cap[1] = 8;
         for (int wv = DD_WAVES; wv >= 1; wv--) {
             ddk::KernelArgs tmp = A;
-            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, true, tmp);
+            const size_t l = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, wv, true, pl.G, tmp);
             if (l > 160u * 1024u) continue;
             int total = (int)((160u * 1024u) / l) * wv;
             if (total > 8) total = 8;
@@ -178,7 +203,7 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     }
     pl.waves = bw[pl.gbt ? 1 : 0];
     pl.waves_per_cu = best[pl.gbt ? 1 : 0];
-    pl.lds = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, pl.waves, pl.gbt, A);
+    pl.lds = lds_layout(pl.K, pl.Dt, max_read_len, n_qual, pl.waves, pl.gbt, pl.G, A);
     pl.grid_cap = 0;
     pl.scratch_bytes = 0;
     if (pl.gbt) {
@@ -301,7 +326,25 @@ static thread_local int32_t g_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pe
 static thread_local char g_kernel_name[64] = "dd_hmm_kernel";
 static thread_local int g_last_direct = 0;     // output arrays the last host-pointer call on this thread let the kernels write in place
 static thread_local int g_last_fold = 0;       // the last main-model launch used the FOLD build (hmm_kernel.hip)
+static thread_local int g_last_G = 1;          // ... pairs per wavefront of that launch
 static thread_local int g_last_occ = 0;        // ... the build variant compiled for that many waves per SIMD (0 = the build's usual occupancy)
+
+// Launch log of the last dd_launch_device / dd_compute_likelihoods call on this host thread (dd_launch_log): one record per main-model
+// kernel launch.  With DD_LAUNCH_TIMING=1 (diagnostics) every launch is bracketed by HIP events and its duration is filled in when the
+// log is read (dd_launch_log synchronises on them).
+struct LaunchRec {
+    int32_t v[DD_LAUNCH_LOG_FIELDS];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+static thread_local std::vector<LaunchRec> g_launch_log;
+static void launch_log_clear()
+{
+    for (auto &r : g_launch_log) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    g_launch_log.clear();
+}
 
 #ifdef DD_STAMPS
 static unsigned long long *g_dbg = nullptr;
@@ -315,7 +358,7 @@ const char *dd_last_error(void) { return g_err.c_str(); }
 const char *dd_kernel_name(void)
 {   // the template instance this host thread launched last, as rocprofv3 prints it (inside "void ddk::...(ddk::KernelArgs)")
     const int K = g_last_launch[0], D = g_last_launch[1];
-    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s, %s, %d>", K, D % 100, D >= 100 ? "true" : "false", g_last_fold ? "true" : "false", g_last_occ);
+    if (K > 0 && D > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_hmm_kernel<%d, %d, %s, %s, %d, %d>", K, D % 100, D >= 100 ? "true" : "false", g_last_fold ? "true" : "false", g_last_occ, g_last_G);
     else if (K > 0) snprintf(g_kernel_name, sizeof(g_kernel_name), "dd_faster_kernel");
     return g_kernel_name;
 }
@@ -325,6 +368,20 @@ int dd_last_direct_outputs(void) { return g_last_direct; }
 void dd_last_launch(int32_t out[8])
 {   // K, D build, waves per workgroup, LDS bytes per workgroup, grid, read split, LDS per wave, shared LDS
     for (int i = 0; i < 8; i++) out[i] = g_last_launch[i];
+}
+
+int dd_launch_log(int32_t *out, int max_records)
+{   // see include/dindel_hmm.h
+    const int n = (int)g_launch_log.size();
+    for (int i = 0; i < n && i < max_records && out; i++) {
+        LaunchRec &r = g_launch_log[(size_t)i];
+        if (r.e0 && r.e1) {
+            float ms = 0.f;
+            if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) r.v[15] = (int32_t)(ms * 1000.f + 0.5f);
+        }
+        memcpy(out + (size_t)i * DD_LAUNCH_LOG_FIELDS, r.v, sizeof(r.v));
+    }
+    return n;
 }
 
 void dd_release_cache(void)
@@ -607,7 +664,6 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
     return T_END;
 }
 
-static const int kHapClassBounds[DD_N_HAP_CLASSES] = {62, 126, 190, 254, 318, 382, 446, 510, 574, 638, 702, DD_MAX_HAP_LEN};   // 64*K - 2
 static const int kReadClassBounds[2] = {160, DD_MAX_READ_LEN};
 
 int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out)
@@ -626,7 +682,7 @@ int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t 
             int c = 0;
             if (!skip) {
                 if (len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766 in a window that is not flagged in win_skip");
-                while (len > kHapClassBounds[c]) c++;
+                c = hap_class_of(len);
                 if (len > out->hap_class_max[c]) out->hap_class_max[c] = len;
             }
             cls[(size_t)h] = c;              // haplotypes of skipped windows ride in class 0: the kernel only marks their pairs
@@ -889,10 +945,10 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     // reads (tools/coverage_sweep.py: 2 reads per window ran at half the rate with idle waves in every workgroup)
     const int64_t avg_reads_w = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
     {
-        const int w2 = waves_for_reads(avg_reads_w, waves, pl.waves_per_cu);
+        const int w2 = waves_for_reads((avg_reads_w + pl.G - 1) / pl.G, waves, pl.waves_per_cu);   // a wavefront takes G reads at a time
         if (w2 != waves) {
             waves = w2;
-            lds = lds_layout(K, Dt, cls_read, b->n_qual, waves, pl.gbt, A);
+            lds = lds_layout(K, Dt, cls_read, b->n_qual, waves, pl.gbt, pl.G, A);
         }
     }
     if (pl.gbt) {
@@ -912,7 +968,7 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     // workgroups the chip holds at once (one-shot grids; a persistent GBT grid is capped to that number below anyway)
     int64_t resident = 256 * (int64_t)std::max(1, std::min((int)((160u * 1024u) / (lds ? lds : 1)), pl.waves_per_cu / waves));
     if (getenv("DD_SPLIT_NO_ROUNDS")) resident = 0;                            // A/B only: the rule before round 3
-    const int64_t split = pick_split(hap_end - hap_begin, avg_reads, waves, target_blocks, resident);
+    const int64_t split = pick_split(hap_end - hap_begin, (avg_reads + pl.G - 1) / pl.G, waves, target_blocks, resident);
     A.n_split = (int32_t)split;
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.item_begin = (int32_t)(hap_begin * split);
@@ -936,16 +992,27 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     // back-pointers, K = 2 at D build 6 with scratch back-pointers, K = 2 at D build 11 with LDS back-pointers — and every haplotype
     // of this launch leaves position 64 K - 1 idle (numS <= 64 K - 1)
     const bool fold_build = pl.gbt ? (K == 2 && Dt == 6) : ((K <= 2 && Dt == 6) || (K == 2 && Dt == 11));     // the builds measured to gain from it
-    const bool fold = fold_build && 64 * K >= cls_hap + 3 && !getenv("DD_NO_FOLD");
+    const bool fold = pl.G == 1 && fold_build && 64 * K >= cls_hap + 3 && !getenv("DD_NO_FOLD");
     g_last_fold = fold ? 1 : 0;
     g_last_occ = (pl.gbt && pl.two_waves) ? 2 : 0;
-    const int build = (fold ? DD_BUILD_FOLD : 0) | ((pl.gbt && pl.two_waves) ? DD_BUILD_TWO_WAVES : 0);
+    const int build = (fold ? DD_BUILD_FOLD : 0) | ((pl.gbt && pl.two_waves) ? DD_BUILD_TWO_WAVES : 0) | (pl.G == 2 ? DD_BUILD_HALF : 0);
+    g_last_G = pl.G;
+    LaunchRec rec;
+    {
+        const int32_t v[DD_LAUNCH_LOG_FIELDS] = {K, pl.G, Dt, pl.gbt ? 1 : 0, fold ? 1 : 0, waves, (int32_t)lds, (int32_t)grid, (int32_t)split,
+                                                 hap_end - hap_begin, cls_hap, lc ? lc->min_read_len : 1, cls_read, pl.waves_per_cu, g_last_occ, -1};
+        memcpy(rec.v, v, sizeof(v));
+    }
+    static const bool timing = getenv("DD_LAUNCH_TIMING") != nullptr;
+    if (timing) { HIP_TRY(hipEventCreate(&rec.e0)); HIP_TRY(hipEventCreate(&rec.e1)); HIP_TRY(hipEventRecord(rec.e0, st)); }
     HIP_TRY(ddk::launch_hmm(K, Dt, pl.gbt, build, A, (unsigned)grid, waves, lds, st));
+    if (timing) HIP_TRY(hipEventRecord(rec.e1, st));
+    g_launch_log.push_back(rec);
     if (r->onHap && r->offHapHMQ && (!lc || lc->run_onhap)) HIP_TRY(ddk::launch_onhap(A, st));
     return DD_SUCCESS;
 }
 
-int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[8])
+int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[10])
 {
     int rc = check_params(p);
     if (rc) return rc;
@@ -956,9 +1023,11 @@ int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qu
     ddk::KernelArgs A;
     memset(&A, 0, sizeof(A));
     if ((rc = make_plan(p, max_hap_len, max_read_len, n_qual, pl, A))) return rc;
-    const int waves = waves_for_reads(avg_reads, pl.waves, pl.waves_per_cu);
+    const int waves = waves_for_reads((avg_reads + pl.G - 1) / pl.G, pl.waves, pl.waves_per_cu);
+    out[8] = pl.G; out[9] = 0;
+    avg_reads = (avg_reads + pl.G - 1) / pl.G;   // units of work per haplotype: a wavefront takes G reads at a time
     out[0] = pl.K; out[1] = pl.Dt; out[2] = pl.gbt ? 1 : 0; out[3] = waves;
-    out[5] = (int32_t)lds_layout(pl.K, pl.Dt, max_read_len, n_qual, waves, pl.gbt, A);
+    out[5] = (int32_t)lds_layout(pl.K, pl.Dt, max_read_len, n_qual, waves, pl.gbt, pl.G, A);
     out[4] = (int32_t)pick_split(n_haps, avg_reads, waves, 4096,
                                  256 * (int64_t)std::max(1, std::min((int)((160u * 1024u) / (out[5] > 0 ? (unsigned)out[5] : 1u)), pl.waves_per_cu / waves)));
     out[6] = (int32_t)((pl.scratch_bytes >> 10) & 0x7fffffff);
@@ -968,6 +1037,7 @@ int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qu
 
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
+    launch_log_clear();
     if (b && b->classes && b->hap_class_list) {
         // ragged batch: one launch per non-empty (haplotype class, read class), onHap once at the end
         const dd_length_classes *C = b->classes;
@@ -1188,6 +1258,7 @@ struct StageClock {
 static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_batch *b, dd_result *r, int device)
 {
     StageClock clk;
+    launch_log_clear();
     int rc = check_params(p);
     if (rc) return rc;
     if (!r || !r->ll || !r->status) return fail(DD_ERR_INVALID, "ll and status outputs are required");
@@ -1253,7 +1324,6 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     // Ragged batches: haplotypes are grouped by the lane tiling they need (K) and reads by length class, and each
     // non-empty (K class, length class) gets its own launches — a single 170-bp haplotype or 250-bp read no longer
     // drags every pair of the batch onto the K=3 / long-read build.
-    const int *kHapBounds = kHapClassBounds;
     // reads: one class up to 160 bp (LDS back-pointer tile still leaves >= 8 waves per CU), one for longer reads
     // (HBM-scratch build).  Finer read classes cost more in repeated per-haplotype setup than they gain
     // (tools/ragged_bench.py: 5000 ragged windows 0.2125 s with haplotype classes only, 0.2532 s with five read classes,
@@ -1267,7 +1337,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
             const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
             size_t c = 0;
             if (!win_skip[(size_t)w]) {          // haplotypes of skipped windows ride in class 0 (their pairs are only marked)
-                while (len > kHapBounds[c]) c++;
+                c = (size_t)hap_class_of(len);
                 if (len > hcls[c].max_hap) hcls[c].max_hap = len;
             }
             hcls[c].haps.push_back((int32_t)h);

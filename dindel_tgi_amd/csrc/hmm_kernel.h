@@ -5,7 +5,8 @@
 #include <stdint.h>
 #include "../../include/dindel_hmm.h"
 
-#define DD_WAVES 4   /* max wavefronts per workgroup: one per SIMD of a CU, one pair in flight per wave */
+#define DD_WAVES 4   /* max wavefronts per workgroup: one per SIMD of a CU, one pair (two in the half-wave builds) in flight per wave */
+#define DD_HALF_CHUNK 256   /* half-wave builds (two pairs per wavefront): reads of a window ordered at a time (LDS keys, capi.cpp sizes them) */
 
 /* layout of the host-built table block (dd_build_tables) */
 enum {
@@ -70,6 +71,9 @@ struct KernelArgs {
     uint32_t lds_off_L, lds_off_E, lds_off_N, lds_off_Q, lds_off_C, lds_off_Y, lds_shared_bytes, lds_wave_bytes;
     int32_t n_qual;
     uint32_t lds_off_A, lds_off_I, lds_off_rdE, lds_off_rdC, lds_off_rdQ, lds_off_ms, lds_off_bt;
+    /* half-wave builds: bytes of one pair's rows inside a wavefront's region (rows of pair q at q * lds_group_bytes; the back-pointer tile
+     * is the wavefront's), and the block-shared sort keys */
+    uint32_t lds_group_bytes, lds_off_S;
 };
 
 /* Workgroups are dealt round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own L2.  The haplotypes of a
@@ -89,6 +93,7 @@ __device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
  * DD_BUILD_TWO_WAVES: the K = 3 / D = 6 scratch build compiled for 2 waves per SIMD instead of 3 */
 #define DD_BUILD_FOLD 1
 #define DD_BUILD_TWO_WAVES 2
+#define DD_BUILD_HALF 4       /* two pairs per wavefront on 32-lane halves (K positions per lane of a half): K = 1, 2, 3, 5, 7 */
 hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */

@@ -93,14 +93,25 @@ __device__ __forceinline__ double dmax(double a, double b)
     return r;
 }
 
-__device__ __forceinline__ double wave_max(double v)
+// G pairs per wavefront (G = 1 or 2): a pair's states live on a group of W = 64 / G consecutive lanes.  The cross-lane steps of a pair
+// stay inside its group: xor-shuffles with offsets below W, the group's W bits of a ballot.  Control flow may diverge BETWEEN the two
+// groups of a wavefront (different reads), never inside one: every lane of a group holds the same per-read values.
+template <int G>
+__device__ __forceinline__ double group_max(double v)
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 32 / G; off >= 1; off >>= 1) {
         const double o = __shfl_xor(v, off);
         v = o > v ? o : v;
     }
     return v;
+}
+// the group's bits of a ballot, lane 0 of the group in bit 0 (G = 1: the ballot itself)
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool p, int grp)
+{
+    const unsigned long long b = __ballot(p);
+    if constexpr (G == 1) return b; else return (b >> (grp * 32)) & 0xffffffffull;
 }
 
 // arg max over one HMM slice with the reference's scan semantics (ObservationModelFB.cpp:1096-1102,
@@ -108,8 +119,8 @@ __device__ __forceinline__ double wave_max(double v)
 // more than EPS.  If exactly one state lies within 3e-10 of the true maximum M, that scan provably ends
 // on it (every earlier incumbent is <= M-3e-10 < M-EPS, nothing later exceeds M+EPS), so the parallel
 // max is exact.  Otherwise (near-ties, e.g. repeats) the scan is replayed verbatim from LDS.
-template <int K>
-__device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double (&vI)[K], int x0, int numS,
+template <int K, int G>
+__device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double (&vI)[K], int x0, int numS, int grp,
                                              double *ldsA, double *ldsI, double &best, int &idx)
 {
     double m = NEG_INF;
@@ -118,12 +129,12 @@ __device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double
         m = vA[k] > m ? vA[k] : m;
         m = vI[k] > m ? vI[k] : m;
     }
-    m = wave_max(m);
+    m = group_max<G>(m);
     const double thr = m - 3e-10;
     int cnt = 0, cand = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const unsigned long long ba = __ballot(vA[k] >= thr), bi = __ballot(vI[k] >= thr);
+        const unsigned long long ba = group_ballot<G>(vA[k] >= thr, grp), bi = group_ballot<G>(vI[k] >= thr, grp);
         cnt += __popcll(ba) + __popcll(bi);
         if (ba) cand = (__ffsll((long long)ba) - 1) * K + k;
         if (bi) cand = numS + (__ffsll((long long)bi) - 1) * K + k;
@@ -155,6 +166,9 @@ __device__ __forceinline__ void mark_unsupported(const dd_result &o, int64_t pai
     if (o.offHapHMQ) o.offHapHMQ[pair] = 1;
 }
 
+#ifndef DD_LEAN_RULE
+#define DD_LEAN_RULE(K, D, GBT) ((GBT) && ((D) > 7 || (K) >= 3))
+#endif
 template <int K, int D> struct BtPack {
     static constexpr int CB = (D <= 7) ? 3 : 4;
     static constexpr int PB = CB + 1;
@@ -174,7 +188,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // D = 6 scratch build at 3 waves/SIMD (168 VGPRs, a few spills outside the sweeps) gains 10-12 % (231.7 -> 207.2 ms per 3,000 windows of
 // 160-bp haplotypes); the D = 11 one loses 14 % to its spills and stays at 2, as does K = 4.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K, D, GBT) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : (((K) <= 4 && (GBT)) ? 2 : 1))
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT, G) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : ((((K) <= 5 || (G) == 2) && (GBT)) ? 2 : 1))
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
@@ -185,17 +199,27 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // OCC: waves per SIMD the register allocator is held to when it is not the rule above (0 = the rule).  One build uses it: K = 3 at D = 6
 // with scratch back-pointers also exists at 2 waves per SIMD, for reads so long (> ~250 bp) that LDS keeps fewer than 12 waves on
 // the CU anyway — there the 3-wave build's spills cost 9 % and buy nothing (profiles/r03/plan_check.jsonl).
-template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0>
-__global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SIMD(K, D, GBT)) dd_hmm_kernel(const KernelArgs P)
+// G: pairs a wavefront works on at a time.  G = 2 (round 4): two reads of the haplotype side by side on the two 32-lane halves, K
+// positions per lane of a half, so a pair costs K / 2 lane-positions per read base instead of ceil((Hs + 2) / 64): haplotypes of
+// 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), <= 62 bp as K = 2 / 1 halves.
+// The two reads advance base by base together (their trip counts are padded to the longer one, the shorter one's lanes masked off), so
+// the workgroup first orders the window's reads by (bMid, bases right of bMid) and a wavefront takes two consecutive ranks.  Every
+// per-read quantity that the G = 1 build keeps on the scalar unit is a per-lane value here, equal across the lanes of a half.
+template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0, int G = 1>
+__global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SIMD(K, D, GBT, G)) dd_hmm_kernel(const KernelArgs P)
 {
+    static_assert(G == 1 || (G == 2 && !FOLD), "two pairs per wavefront: 32-lane halves, end states in their one-lane blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int wlane = tid & 63;                    // lane of the wavefront
+    constexpr int W = 64 / G;                      // lanes per pair
+    const int grp = (G == 1) ? 0 : (wlane >> 5);   // which of the wavefront's pairs this lane works for
+    const int lane = (G == 1) ? wlane : (wlane & (W - 1));   // lane within the pair's group: owner of positions lane*K .. lane*K+K-1
     // wave index is uniform across the 64 lanes: tell the compiler, so that everything per read (offsets,
     // lengths, bMid, loop counters, the traceback chain) lives on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthr = blockDim.x, nwav = blockDim.x >> 6;   // 1..4 waves (host picks what fits LDS best)
-    const int NP = 64 * K;
+    const int NP = W * K;
     constexpr bool foldLO = FOLD;                   // (host: only for haplotypes with numS <= NP - 1)
     const int Dr = P.D;                             // real D (== D unless the generic D=12 build is used)
     const double *T = P.tables;
@@ -208,13 +232,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     double *shN = reinterpret_cast<double *>(smem + P.lds_off_N);  // [NP+D+2] logProbNoError per state
     double *shQ = reinterpret_cast<double *>(smem + P.lds_off_Q);  // [n_qual][4] eq, uq, log10(1-q), q
     // ---------------- wave-private region ----------------
-    unsigned char *wbase = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
+    unsigned char *wave_base = smem + P.lds_shared_bytes + (size_t)wave * P.lds_wave_bytes;
+    unsigned char *wbase = (G == 1) ? wave_base : wave_base + (size_t)grp * P.lds_group_bytes;   // the pair's own rows (G = 1: the wavefront's)
     // one HMM slice as the neighbours see it: {value, emission log of that state for the slice's read base}
     // K interleaved arrays (state s lives in array s % K at index s / K, PADQ pad entries either side) so that every
     // wave-wide ds_read_b128 / ds_write_b128 touches consecutive 16-byte slots: a flat [state] layout puts lanes l and
     // l+8 on the same banks for K = 2 (2-way conflict on every neighbour read; SQ_LDS_BANK_CONFLICT was 41 % of LDS cycles)
     constexpr int PADQ = (D + K - 1) / K;
-    constexpr int AQ = 64 + 2 * PADQ;
+    constexpr int AQ = W + 2 * PADQ;
     double2 *rowA = reinterpret_cast<double2 *>(wbase + P.lds_off_A);     // [K][AQ]
     double *rowI = reinterpret_cast<double *>(wbase + P.lds_off_I);       // [1 + NP + 1]   state s -> rowI[1+s]
     double *rdE = reinterpret_cast<double *>(wbase + P.lds_off_rdE);      // [Lmax][2]  eq, uq per read base
@@ -224,8 +249,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // LEAN (HBM-scratch builds with D > 7 or K >= 3): the two [K][D] per-lane constant arrays (88 VGPRs at K = 2, D = 11) do not fit next
     // to the slice window at 3 waves/SIMD; the Inc constants come from a block-shared LDS table instead (LDS is idle in
     // this build) and the Dec jump penalties are formed on the fly from E[x] and a broadcast (y-1)*II.
-    constexpr bool LEAN = GBT && (D > 7 || K >= 3);
-    double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][64] lp_y(src)+Nn[src]
+    constexpr bool LEAN = DD_LEAN_RULE(K, D, GBT);
+    double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][W] lp_y(src)+Nn[src]
     double *shY = reinterpret_cast<double *>(smem + P.lds_off_Y);  // LEAN: [D] (y-1)*II
     typedef BtPack<K, D> BP;
     typedef typename BtWord<BP::BYTES>::type btword_t;
@@ -234,7 +259,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     if constexpr (GBT)
         bt = reinterpret_cast<btword_t *>(P.bt_scratch) + (size_t)(blockIdx.x * nwav + wave) * (size_t)P.bt_rows * 64;
     else
-        bt = reinterpret_cast<btword_t *>(wbase + P.lds_off_bt);
+        bt = reinterpret_cast<btword_t *>(wave_base + P.lds_off_bt);
+    // G = 2: the workgroup's order of a chunk of the window's reads (sort keys, then read index by rank)
+    uint32_t *skey = reinterpret_cast<uint32_t *>(smem + P.lds_off_S);     // [DD_HALF_CHUNK]
+    uint16_t *sord = reinterpret_cast<uint16_t *>(skey + DD_HALF_CHUNK);   // [DD_HALF_CHUNK]
 
     for (int i = tid; i < 4 * P.n_qual; i += nthr) shQ[i] = T[T_QUAL + i];
     for (int i = tid; i < 256; i += nthr) shLut[i] = P.sym_lut ? P.sym_lut[i] : (unsigned char)builtin_symbol((unsigned)i);
@@ -301,8 +329,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     __syncthreads();
 
     if constexpr (LEAN) {
-        for (int i = tid; i < K * D * 64; i += nthr) {
-            const int l = i & 63, ky = i >> 6, k = ky / D, y = ky - k * D + 1;
+        for (int i = tid; i < K * D * W; i += nthr) {
+            const int l = i & (W - 1), ky = i / W, k = ky / D, y = ky - k * D + 1;
             const int src = l * K + k + y;
             double c = NEG_INF;
             if (src <= RO && y <= Dr) {
@@ -396,50 +424,108 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     const int nv = P.hap_var_off ? (P.hap_var_off[g + 1] - P.hap_var_off[g]) : 0;
 
     STAMP(0);
+    // ---- bMid: ObservationModelFB::Init (ObservationModelFB.cpp:51-99) ----
+    auto bmid_of = [&](int r, int L) -> int {
+        int bMid;
+        const uint32_t hapEnd = hapStart + (uint32_t)Hs;
+        const uint32_t mReadStart = P.read_start[r];
+        const uint32_t readEnd = mReadStart + (uint32_t)L - 1u;
+        if ((P.read_flags[r] & 1) || mReadStart > hapEnd || readEnd < hapStart) {
+            bMid = L / 2;
+        } else {
+            const uint32_t olStart = (hapStart > mReadStart) ? hapStart : mReadStart;
+            const uint32_t olEnd = (hapEnd > readEnd) ? readEnd : hapEnd;
+            const int mid = ((int)olEnd - (int)olStart) / 2 + (int)olStart;
+            bMid = mid - (int)mReadStart;
+        }
+        if (P.bMid != -1) bMid = P.bMid;
+        if (bMid < 0) bMid = 0;
+        if (bMid >= L) bMid = L - 1;
+        return bMid;
+    };
+    // a pair the reference throws "hapSize error." for (ObservationModelFB.cpp:47): status, no coverage flags
+    auto mark_hapsize = [&](int ri, int first, int step) {
+        const int64_t pair = pair_base + ri;
+        if (first == 0) {
+            P.out.status[pair] = DD_PAIR_HAPSIZE;
+            P.out.ll[pair] = 0.0;
+        }
+        if (nv > 0) {
+            const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
+            for (int i = first; i < nv; i += step) {
+                if (P.out.var_covered) P.out.var_covered[vb + i] = 0;
+                if (P.out.var_fcov) P.out.var_fcov[vb + i] = 0;
+            }
+        }
+    };
     // ======================= loop over this wave's reads =======================
-    for (int ri = split * nwav + wave; ri < R; ri += P.n_split * nwav) {
+    // G = 1: the wavefront takes reads split*nwav + wave, + n_split*nwav, ...  G = 2: the window's reads are taken in chunks of
+    // DD_HALF_CHUNK; every workgroup of the haplotype orders the chunk's reads of this launch's length class by (bMid, L) — the two
+    // pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) + max(bMid1, bMid2) sweeps, so they should agree in both — and its wavefronts
+    // take pairs of consecutive ranks the same round-robin way.  Results do not depend on the order.
+    const int nChunks = (G == 1) ? 1 : (R + DD_HALF_CHUNK - 1) / DD_HALF_CHUNK;
+    for (int chunk0 = 0, ci = 0; ci < nChunks; ci++, chunk0 += DD_HALF_CHUNK) {
+    int nch = R;                                   // reads this pass hands out (G = 2: the chunk's reads of this length class)
+    if constexpr (G > 1) {
+        const int nraw = (R - chunk0 < DD_HALF_CHUNK) ? R - chunk0 : DD_HALF_CHUNK;
+        __syncthreads();                           // the previous chunk's order is no longer read
+        for (int t = tid; t < nraw; t += nthr) {
+            const int rr = r0 + chunk0 + t;
+            const int L = P.read_seq_off[rr + 1] - P.read_seq_off[rr];
+            uint32_t key = 0xffffffffu;            // not of this launch's length class: behind every read that is
+            if (L >= P.len_min && L <= P.len_max) {
+                if (!hap_ok) { if (split == 0) mark_hapsize(chunk0 + t, 0, 1); }
+                else key = ((uint32_t)bmid_of(rr, L) << 11) | (uint32_t)((L - 1) & 2047);
+            }
+            skey[t] = key;
+        }
+        __syncthreads();
+        for (int t = tid; t < nraw; t += nthr) {
+            const uint32_t k = skey[t];
+            int rank = 0;
+            for (int j = 0; j < nraw; j++) {
+                const uint32_t kj = skey[j];
+                rank += (kj < k || (kj == k && j < t)) ? 1 : 0;
+            }
+            sord[rank] = (uint16_t)t;
+        }
+        __syncthreads();
+        int lo = 0, hi = nraw;                     // reads that take part = ranks in front of the first 0xffffffff key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (skey[sord[mid]] != 0xffffffffu) lo = mid + 1; else hi = mid;
+        }
+        nch = __builtin_amdgcn_readfirstlane(lo);
+    }
+    for (int rb = (split * nwav + wave) * G; rb < nch; rb += P.n_split * nwav * G) {
+        // G = 2: the second pair of the last wavefront may be missing: its lanes run the code with an empty read and store nothing
+        const bool live = (G == 1) || (rb + grp < nch);
+        const int ri = (G == 1) ? rb : chunk0 + (live ? (int)sord[rb + grp] : (int)sord[rb]);
         const int r = r0 + ri;
         const int64_t pair = pair_base + ri;
         const int so = P.read_seq_off[r];
-        const int L = P.read_seq_off[r + 1] - so;
+        const int Lread = P.read_seq_off[r + 1] - so;
+        const int L = live ? Lread : 0;
 
-        if (L < P.len_min || L > P.len_max) continue;      // another length-class launch owns this read
-        if (!hap_ok) {
-            if (lane == 0) {
-                P.out.status[pair] = DD_PAIR_HAPSIZE;
-                P.out.ll[pair] = 0.0;
-            }
-            if (nv > 0) {                                      // coverage flags of a pair the reference throws for: none
-                const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
-                for (int i = lane; i < nv; i += 64) {
-                    if (P.out.var_covered) P.out.var_covered[vb + i] = 0;
-                    if (P.out.var_fcov) P.out.var_fcov[vb + i] = 0;
-                }
-            }
-            continue;
+        if constexpr (G == 1) {
+            if (L < P.len_min || L > P.len_max) continue;      // another length-class launch owns this read
+            if (!hap_ok) { mark_hapsize(ri, lane, 64); continue; }
         }
 
-        // ---- bMid: ObservationModelFB::Init (ObservationModelFB.cpp:51-99) ----
-        int bMid;
-        {
-            const uint32_t hapEnd = hapStart + (uint32_t)Hs;
-            const uint32_t mReadStart = P.read_start[r];
-            const uint32_t readEnd = mReadStart + (uint32_t)L - 1u;
-            if ((P.read_flags[r] & 1) || mReadStart > hapEnd || readEnd < hapStart) {
-                bMid = L / 2;
-            } else {
-                const uint32_t olStart = (hapStart > mReadStart) ? hapStart : mReadStart;
-                const uint32_t olEnd = (hapEnd > readEnd) ? readEnd : hapEnd;
-                const int mid = ((int)olEnd - (int)olStart) / 2 + (int)olStart;
-                bMid = mid - (int)mReadStart;
-            }
-            if (P.bMid != -1) bMid = P.bMid;
-            if (bMid < 0) bMid = 0;
-            if (bMid >= L) bMid = L - 1;
+        const int bMid = live ? bmid_of(r, L) : 0;
+        // trip counts of the two passes; G = 2: the wavefront runs the longer of its two pairs' counts, the other pair's lanes wait masked
+        const int nInc = L - 1 - bMid, nDec = bMid;
+        int nIncW = nInc, nDecW = nDec;
+        if constexpr (G > 1) {
+            const int oi = __shfl_xor(nInc, 32), od = __shfl_xor(nDec, 32);
+            nIncW = oi > nInc ? oi : nInc;
+            nDecW = od > nDec ? od : nDec;
+            nIncW = __builtin_amdgcn_readfirstlane(nIncW);
+            nDecW = __builtin_amdgcn_readfirstlane(nDecW);
         }
 
         // ---- stage the read: base codes + emission logs (setupReadObservationPotentials :220-252) ----
-        for (int b = lane; b < L; b += 64) {
+        for (int b = lane; b < L; b += W) {
             const int qi = P.read_qidx[so + b];
             rdC[b] = shLut[(unsigned char)P.read_seq[so + b]];
             rdQ[b] = (unsigned char)qi;
@@ -450,9 +536,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // pads of the slice arrays (the join's near-tie replay may have used the buffer as scratch)
-        for (int i = lane; i < 2 * PADQ * K; i += 64) {
+        for (int i = lane; i < 2 * PADQ * K; i += W) {
             const int kk = i / (2 * PADQ), j = i - kk * (2 * PADQ);
-            rowA[kk * AQ + (j < PADQ ? j : 64 + j)] = make_double2(NEG_INF, 0.0);
+            rowA[kk * AQ + (j < PADQ ? j : W + j)] = make_double2(NEG_INF, 0.0);
         }
         STAMP(1);   // bMid + staging
         double a[K], in[K];           // current slice: "on base x" and "inserted at x"
@@ -486,9 +572,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             }
             if (foldLO && lane == 63) { a[K - 1] = 0.0; in[K - 1] = 0.0; }      // beta[L-1][LO] = beta[L-1][numS] = 0, at LO's position in this pass
             auto cinc = [&](int k, int y) -> double {       // y = 1..D
-                if constexpr (LEAN) return shC[(k * D + y - 1) * 64 + lane]; else return cInc[k][y - 1];
+                if constexpr (LEAN) return shC[(k * D + y - 1) * W + lane]; else return cInc[k][y - 1];
             };
-            for (int b = L - 1; b > bMid; b--) {
+            auto incStep = [&](const int b) __attribute__((always_inline)) {
                 const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
                 const int col = rdC[b];
                 double v[D + K], ov[D + K];
@@ -581,7 +667,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     in[k] = ni[k];
                     word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
-                bt[b * 64 + lane] = word;                           // btb[b-1] stored at row b
+                bt[b * 64 + wlane] = word;                          // btb[b-1] stored at row b
+            };
+            if constexpr (G == 1) {
+                for (int b = L - 1; b > bMid; b--) incStep(b);
+            } else {
+                for (int it = 0; it < nIncW; it++)
+                    if (it < nInc) incStep(L - 1 - it);
             }
         }
         STAMP(3);   // Inc passes
@@ -620,7 +712,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     for (int y = 2; y <= D; y++) lpDec[k][y - 1] = (y > Dr) ? NEG_INF : eIn[k] + (double)(y - 1) * II;
                 }
             }
-            for (int b = 1; b <= bMid; b++) {
+            auto decStep = [&](const int b) __attribute__((always_inline)) {
                 const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
                 const int col = rdC[b - 1];
                 double v[D + K], ov[D + K];
@@ -710,7 +802,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     in[k] = ni[k];
                     word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
-                bt[b * 64 + lane] = word;
+                bt[b * 64 + wlane] = word;
+            };
+            if constexpr (G == 1) {
+                for (int b = 1; b <= bMid; b++) decStep(b);
+            } else {
+                for (int it = 1; it <= nDecW; it++)
+                    if (it <= nDec) decStep(it);
             }
         }
         STAMP(2);   // Dec passes
@@ -774,12 +872,17 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     on = vI[k] > on ? vI[k] : on;
                 }
             }
-            llOn = wave_max(on);
+            llOn = group_max<G>(on);
             llOff = vA[0] > vI[0] ? vA[0] : vI[0];                          // states 0 and numS (:1104-1105); lane 0 only
-            slice_argmax<K>(vA, vI, x0, numS, scanA, scanI, ll, mapRMQ);
-            slice_argmax<K>(hA, hI, x0, numS, scanA, scanI, llHMQ, mapHMQ);
+            slice_argmax<K, G>(vA, vI, x0, numS, grp, scanA, scanI, ll, mapRMQ);
+            slice_argmax<K, G>(hA, hI, x0, numS, grp, scanA, scanI, llHMQ, mapHMQ);
         }
-        if (with_ro || (ll > -99.0 && llHMQ > -99.0)) break;
+        if constexpr (G == 1) {
+            if (with_ro || (ll > -99.0 && llHMQ > -99.0)) break;
+        } else {
+            // the pass with RO evaluated is the reference's computation for any pair: if one of the two pairs needs it, both redo
+            if (with_ro || __ballot(live && !(ll > -99.0 && llHMQ > -99.0)) == 0ull) break;
+        }
         }
         STAMP(4);   // join
         const int xR = mapRMQ % numS, xH = mapHMQ % numS;
@@ -809,9 +912,18 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             constexpr unsigned chmask = (1u << BP::CB) - 1u, fmask = (1u << BP::PB) - 1u;
             auto fieldAt = [&](int row, int x) -> unsigned {               // per-lane row / position: the PB bits of that state
                 const int src = x / K, sh = (x - src * K) * BP::PB;
-                return (unsigned)(bt[row * 64 + src] >> sh) & fmask;
+                return (unsigned)(bt[row * 64 + grp * W + src] >> sh) & fmask;
             };
-            const int s0 = __builtin_amdgcn_readfirstlane(mapHMQ);
+            // G = 1: the walk is wave-uniform and runs on the scalar unit; G = 2: every lane of a group holds its pair's walk
+            const int s0 = (G == 1) ? __builtin_amdgcn_readfirstlane(mapHMQ) : mapHMQ;
+            auto group_lane_value = [&](unsigned v, int l) -> unsigned {      // v of the group's lane l (l uniform in the group)
+                if constexpr (G == 1) return (unsigned)__builtin_amdgcn_readlane((int)v, l);
+                else return (unsigned)__shfl((int)v, grp * W + l);
+            };
+            auto group_uniform = [&](unsigned v) -> unsigned {                // v is equal across the group's lanes
+                if constexpr (G == 1) return (unsigned)__builtin_amdgcn_readfirstlane((int)v); else return v;
+            };
+            constexpr unsigned long long fullRun = (G == 1) ? ~0ull : 0xffffffffull;
             if (lane == 0) ms[bMid] = (int16_t)s0;
             // ---- towards base 0: mapState[b-1] = btf[b][mapState[b]] ----
             {
@@ -819,22 +931,22 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 while (b > 0) {
                     unsigned f;
                     if (!ins && x == 0) {                                  // LO is absorbing in this direction (:1798-1799)
-                        for (int j = lane; j < b; j += 64) ms[j] = 0;
+                        for (int j = lane; j < b; j += W) ms[j] = 0;
                         break;
                     }
                     if (!ins && x != RO) {                                 // diagonal run: rows b, b-1, ...; positions x, x-1, ...
-                        const int maxrun = b < 64 ? b : 64;
+                        const int maxrun = b < W ? b : W;
                         const bool valid = lane < maxrun && x - lane >= 1;
                         f = valid ? fieldAt(b - lane, x - lane) : 0u;
-                        const unsigned long long m = __ballot(valid && (f & chmask) == 1u);
-                        const int run = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+                        const unsigned long long m = group_ballot<G>(valid && (f & chmask) == 1u, grp);
+                        const int run = (m == fullRun) ? W : __builtin_ctzll(~m);
                         if (lane < run) ms[b - 1 - lane] = (int16_t)(x - 1 - lane);
                         b -= run; x -= run;
                         if (b == 0) break;
                         if (run == maxrun || x == 0) continue;             // next 64 rows / reached LO
-                        f = (unsigned)__builtin_amdgcn_readlane((int)f, run);   // the row that ended the run: decode it below
+                        f = group_lane_value(f, run);                      // the row that ended the run: decode it below
                     } else {
-                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b, x));
+                        f = group_uniform(fieldAt(b, x));
                     }
                     // one row, any state.  on base x: ch = jump length y (from x-y), 0 = from the inserted state numS+x-1;
                     // RO: 0 RO, 1 Hs, 2 numS+RO, 3 numS+Hs.  inserted at x: bit set = entered from "on base x", else stays
@@ -858,21 +970,21 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     const int xf = (foldLO && x == 0) ? NP - 1 : x;
                     const unsigned stayCode = (x == 0 ? foldLO : foldRO) ? 2u : 0u;
                     if (!ins) {
-                        const int left = L - 1 - b, maxrun = left < 64 ? left : 64;
+                        const int left = L - 1 - b, maxrun = left < W ? left : W;
                         const bool stay = (x == 0 || x == RO);             // LO / RO
                         const bool valid = lane < maxrun && (stay || x + lane <= Hs);
                         f = valid ? fieldAt(b + 1 + lane, stay ? xf : x + lane) : 0u;
-                        const unsigned long long m = __ballot(valid && (f & chmask) == (stay ? stayCode : 1u));
-                        const int run = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+                        const unsigned long long m = group_ballot<G>(valid && (f & chmask) == (stay ? stayCode : 1u), grp);
+                        const int run = (m == fullRun) ? W : __builtin_ctzll(~m);
                         if (lane < run) ms[b + 1 + lane] = (int16_t)(stay ? x : x + 1 + lane);
                         b += run;
                         if (!stay) x += run;
                         if (b >= L - 1) break;
                         if (run == maxrun) continue;
                         if (!stay && x > Hs) continue;                     // the diagonal ran into RO: next round handles it as a stay run
-                        f = (unsigned)__builtin_amdgcn_readlane((int)f, run);
+                        f = group_lane_value(f, run);
                     } else {
-                        f = (unsigned)__builtin_amdgcn_readfirstlane((int)fieldAt(b + 1, xf));
+                        f = group_uniform(fieldAt(b + 1, xf));
                     }
                     // on base x: ch = jump length y (to x+y), 0 = to the inserted state numS+x; LO: 0 LO, 1 base 1, 2 numS;
                     // RO: 0 RO, else numS+RO.  inserted at x: bit set = leaves to min(x+1, RO) (LO's stays LO), else stays.
@@ -907,7 +1019,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         double mLogBQ = 0.0;
         const double thr = T[TC_BQT];
         int16_t *hp_out = P.out.hpos ? P.out.hpos + hpos_base + (so - rs_base) : nullptr;
-        for (int b0 = 0; b0 < L; b0 += 64) {
+        for (int b0 = 0; b0 < L; b0 += W) {
             const int b = b0 + lane;
             double cb = 0.0;
             bool pIndel = false, pDel = false, pMis = false, pBQT = false, pmmBQT = false, pL = false, pR = false;
@@ -942,12 +1054,12 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 }
                 if (hp_out) hp_out[b] = (int16_t)hp;
             }
-            nIndel += __popcll(__ballot(pIndel)) + __popcll(__ballot(pDel));
-            nMis += __popcll(__ballot(pMis));
-            nmmBQT += __popcll(__ballot(pmmBQT));
-            nMML += __popcll(__ballot(pL));
-            nMMR += __popcll(__ballot(pR));
-            const unsigned long long bq = __ballot(pBQT);
+            nIndel += __popcll(group_ballot<G>(pIndel, grp)) + __popcll(group_ballot<G>(pDel, grp));
+            nMis += __popcll(group_ballot<G>(pMis, grp));
+            nmmBQT += __popcll(group_ballot<G>(pmmBQT, grp));
+            nMML += __popcll(group_ballot<G>(pL, grp));
+            nMMR += __popcll(group_ballot<G>(pR, grp));
+            const unsigned long long bq = group_ballot<G>(pBQT, grp);
             nBQT += __popcll(bq);
             // mLogBQ: the reference adds log10(1-q) base by base in read order (:1404-1407); fp64 + is not
             // associative, so the sum runs serially in that order (adding +0.0 for skipped bases is exact).  The terms
@@ -973,7 +1085,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
+        for (int off = 32 / G; off >= 1; off >>= 1) {
             const int f = __shfl_xor(firstB, off), l2 = __shfl_xor(lastB, off);
             firstB = f < firstB ? f : firstB;
             lastB = l2 > lastB ? l2 : lastB;
@@ -982,9 +1094,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         STAMP(6);   // hpos + counters + mLogBQ
 
         // hapIndelCovered / hapSNPCovered (:1465-1472; AlignedVariant::isCovered Variant.hpp:125-128)
+        const int nvl = live ? nv : 0;                 // (G = 2: a missing second pair stores nothing)
         if (P.out.var_covered && nv > 0) {
             const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
-            for (int i = lane; i < nv; i += 64) {
+            for (int i = lane; i < nvl; i += W) {
                 const int sR = P.hap_var[2 * (P.hap_var_off[g] + i)];
                 const int eR = P.hap_var[2 * (P.hap_var_off[g] + i) + 1];
                 P.out.var_covered[vb + i] = (firstB + P.padCover <= sR && lastB - P.padCover >= eR) ? 1 : 0;
@@ -997,13 +1110,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         if (P.out.var_fcov && P.hap_var_flank && nv > 0) {
             const int64_t vb = P.win_varcov_off[w] + (int64_t)(P.hap_var_off[g] - P.hap_var_off[h0]) * R + (int64_t)ri * nv;
             const bool sel = !offHapHMQ && nIndel == 0;
-            for (int i = 0; i < nv; i++) {
+            for (int i = 0; i < nvl; i++) {
                 const int32_t *fl = P.hap_var_flank + 3 * (size_t)(P.hap_var_off[g] + i);
                 const int left = fl[0] - P.padCover, right = fl[1] + P.padCover, kind = fl[2];
                 int cov = 0;
                 if (sel && kind != 0) {
                     int nmm = 0;
-                    for (int b0 = 0; b0 < L; b0 += 64) {
+                    for (int b0 = 0; b0 < L; b0 += W) {
                         const int b = b0 + lane;
                         bool mm = false;
                         if (b < L) {
@@ -1014,7 +1127,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                                 mm = hb >= left && hb <= right && (int)rdC[b] != hc && (kind == 2 || hc != DD_SYM_N);   // 'N' exempt for DEL (:1992)
                             }
                         }
-                        nmm += __popcll(__ballot(mm));
+                        nmm += __popcll(group_ballot<G>(mm, grp));
                     }
                     const int lo = firstB > left ? firstB : left, hi = lastB < right ? lastB : right;
                     const int csize = (firstB >= 0 && hi >= lo) ? hi - lo + 1 : 0;
@@ -1024,7 +1137,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             }
         }
 
-        if (lane == 0) {
+        if (lane == 0 && live) {
             int status = DD_PAIR_OK;
             if (ll > 0.1) status = DD_PAIR_LLPOS;                         // DInDel.cpp:1722
             else if (ll != ll || ll == NEG_INF || ll == -NEG_INF) status = DD_PAIR_NAN;   // DInDel.cpp:1732
@@ -1048,6 +1161,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         // the next read reuses rdE/rdC/ms/bt of this wave: all of this pair's LDS reads precede (in program
         // order, same wave) the next pair's LDS writes, and DS ops of one wave execute in order.
     }
+    }   // chunks of the window's reads (G = 1: one pass)
     }   // item loop
     STAMP_FLUSH;
 }
@@ -1079,7 +1193,7 @@ __global__ void dd_onhap_kernel(const KernelArgs P)
 }
 #endif
 
-template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0>
+template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0, int G = 1>
 static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
     // The cap on dynamic LDS is a property of the function, not of a launch: it is raised ONCE per template instance (and
@@ -1091,13 +1205,13 @@ static hipError_t launch_one(const KernelArgs &A, dim3 grid, int waves, size_t l
     if (e != hipSuccess) return e;
     const unsigned bit = 1u << (dev & 31);
     if (!(raised.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT, FOLD, OCC>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dd_hmm_kernel<K, D, GBT, FOLD, OCC, G>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_release);
     }
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT, FOLD, OCC>), grid, dim3(waves * 64), lds, st, A);
+    hipLaunchKernelGGL((dd_hmm_kernel<K, D, GBT, FOLD, OCC, G>), grid, dim3(waves * 64), lds, st, A);
     return hipGetLastError();
 }
 
@@ -1106,7 +1220,11 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, u
 {
     const bool fold = (build & DD_BUILD_FOLD) != 0;
     if (K != DD_ONLY_K || Dt != DD_ONLY_D) return hipErrorInvalidValue;
-    if (fold && !gbt) return launch_one<DD_ONLY_K, DD_ONLY_D, false, true>(A, dim3(grid), waves, lds, st);
+    if (build & DD_BUILD_HALF)
+        return gbt ? launch_one<DD_ONLY_K, DD_ONLY_D, true, false, 0, 2>(A, dim3(grid), waves, lds, st)
+                   : launch_one<DD_ONLY_K, DD_ONLY_D, false, false, 0, 2>(A, dim3(grid), waves, lds, st);
+    if constexpr (DD_ONLY_K <= 2) { if (fold && !gbt) return launch_one<DD_ONLY_K, DD_ONLY_D, false, true>(A, dim3(grid), waves, lds, st); }
+    else if (fold) return hipErrorInvalidValue;
     return gbt ? launch_one<DD_ONLY_K, DD_ONLY_D, true>(A, dim3(grid), waves, lds, st)
                : launch_one<DD_ONLY_K, DD_ONLY_D, false>(A, dim3(grid), waves, lds, st);
 }
@@ -1134,16 +1252,31 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
     }
 }
 
+// half-wave builds (two pairs per wavefront): K = 1, 2, 3, 5, 7 positions per lane of a 32-lane half
+template <int D, bool GBT>
+static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
+{
+    switch (K) {
+    case 1: return launch_one<1, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    case 2: return launch_one<2, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    case 3: return launch_one<3, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    case 5: return launch_one<5, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    case 7: return launch_one<7, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 #ifndef DD_INST_D
 #define DD_INST_D 0            // 0: every D build in this unit
 #endif
 hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d11(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
-hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d12(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 #if DD_INST_D == 0 || DD_INST_D == 6
 hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
     const bool fold = (build & DD_BUILD_FOLD) != 0;
+    if (build & DD_BUILD_HALF) return gbt ? launch_half<6, true>(K, A, g, waves, lds, st) : launch_half<6, false>(K, A, g, waves, lds, st);
     if (gbt && K == 3 && (build & DD_BUILD_TWO_WAVES)) return launch_one<3, 6, true, false, 2>(A, g, waves, lds, st);
     if (fold && !gbt && K == 1) return launch_one<1, 6, false, true>(A, g, waves, lds, st);
     if (fold && !gbt && K == 2) return launch_one<2, 6, false, true>(A, g, waves, lds, st);
@@ -1155,13 +1288,15 @@ hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g
 hipError_t launch_hmm_d11(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
     const bool fold = (build & DD_BUILD_FOLD) != 0;
+    if (build & DD_BUILD_HALF) return gbt ? launch_half<11, true>(K, A, g, waves, lds, st) : launch_half<11, false>(K, A, g, waves, lds, st);
     if (fold && !gbt && K == 2) return launch_one<2, 11, false, true>(A, g, waves, lds, st);
     return gbt ? launch_k<11, true>(K, A, g, waves, lds, st) : launch_k<11, false>(K, A, g, waves, lds, st);
 }
 #endif
 #if DD_INST_D == 0 || DD_INST_D == 12
-hipError_t launch_hmm_d12(int K, bool gbt, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+hipError_t launch_hmm_d12(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
+    if (build & DD_BUILD_HALF) return gbt ? launch_half<12, true>(K, A, g, waves, lds, st) : launch_half<12, false>(K, A, g, waves, lds, st);
     return gbt ? launch_k<12, true>(K, A, g, waves, lds, st) : launch_k<12, false>(K, A, g, waves, lds, st);
 }
 #endif
@@ -1172,7 +1307,7 @@ hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, u
     switch (Dt) {
     case 6: return launch_hmm_d6(K, gbt, build, A, dim3(grid), waves, lds, st);
     case 11: return launch_hmm_d11(K, gbt, build, A, dim3(grid), waves, lds, st);
-    case 12: return launch_hmm_d12(K, gbt, A, dim3(grid), waves, lds, st);
+    case 12: return launch_hmm_d12(K, gbt, build, A, dim3(grid), waves, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

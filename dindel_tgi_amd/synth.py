@@ -113,3 +113,47 @@ def tile(pb: PackedBatch, reps: int) -> PackedBatch:
         read_start=np.tile(a["read_start"], reps), read_flags=np.tile(a["read_flags"], reps),
         qual_table=a["qual_table"], mapq_table=a["mapq_table"],
         hap_var_flank=None if pb.hap_var_flank is None else np.tile(pb.hap_var_flank, reps))
+
+
+def concat(parts) -> PackedBatch:
+    """Several batches (same quality / mapping-quality tables) as one: the windows of parts[0], then parts[1], ..."""
+    offs = dict(win_hap_off=0, win_read_off=0, hap_seq_off=0, hap_var_off=0, read_seq_off=0)
+    out = {k: [] for k in PackedBatch.FIELDS}
+    for k in offs:
+        out[k].append(np.zeros(1, np.int64))
+    flank = []
+    for p in parts:
+        for k in PackedBatch.FIELDS:
+            v = p.a[k]
+            if k in offs:
+                out[k].append(v[1:].astype(np.int64) + offs[k])
+                offs[k] += int(v[-1])
+            elif k in ("qual_table", "mapq_table"):
+                out[k] = [v]
+            else:
+                out[k].append(v)
+        flank.append(p.hap_var_flank if p.hap_var_flank is not None else np.empty(0, np.int32))
+    return PackedBatch(hap_var_flank=np.concatenate(flank), **{k: np.concatenate(v) for k, v in out.items()})
+
+
+def generate_ragged(n_windows, seed=0x5EED4, max_reads=400) -> PackedBatch:
+    """Windows in the shapes the reference's own pipeline produces (fixed seed; bench.py's `ragged` leg, tests):
+
+    * reference haplotype = [minRef - 60, maxRef + 60] around the window's candidates (python/makeWindows.py:72-75): 121 bp for a
+      single-position candidate, longer when the candidates span a deletion or are clustered — here 121 + extra, extra = 0 for
+      45 % of the windows, else geometric (mean 9) capped at 40;
+    * 2..12 candidate haplotypes per window (getHaplotypes, DInDel.cpp:1526-1645), each the reference with one insertion or
+      deletion of 1..max_indel bases (max_indel drawn per window from 1..12), so a window's haplotypes have DIFFERENT lengths;
+    * 20..max_reads reads per window (log-uniform), one read length per window out of 36 / 76 / 100 / 150 bp (every fifth
+      window with trimmed reads of mixed lengths), Phred 2..41 base qualities, nine mapping qualities.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    for i in range(n_windows):
+        extra = 0 if rng.random() < 0.45 else int(min(40, rng.geometric(1.0 / 9.0)))
+        H = int(rng.integers(2, 13))
+        R = int(np.exp(rng.uniform(np.log(20.0), np.log(float(max_reads)))))
+        L = int(rng.choice([36, 76, 100, 150], p=[0.1, 0.25, 0.45, 0.2]))
+        parts.append(generate(1, H=H, R=R, L=L, hap_len=121 + extra, seed=int(rng.integers(1, 2 ** 31)), max_indel=int(rng.integers(1, 13)),
+                              vary_read_len=(i % 5 == 4), mixed_quals=True))
+    return concat(parts)

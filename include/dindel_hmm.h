@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 11
+#define DD_ABI_VERSION 12
 
 /* hpos[] sentinel values — reference: MLAlignment.hpp:31-34 */
 #define DD_HPOS_INS (-1)
@@ -254,7 +254,7 @@ int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off
  * non-empty (haplotype class, read class) gets its own launch plan, so one long haplotype or read does not put the whole
  * batch on the slower build.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the
  * summary once on the host (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
-#define DD_N_HAP_CLASSES 12
+#define DD_N_HAP_CLASSES 16
 typedef struct dd_length_classes {
     int32_t hap_class_off[DD_N_HAP_CLASSES + 1];  /* class c owns hap_class_list[hap_class_off[c] .. hap_class_off[c+1])   */
     int32_t hap_class_max[DD_N_HAP_CLASSES];      /* longest haplotype of the class (0 = empty class)                      */
@@ -339,15 +339,24 @@ int dd_map_pairs(const dd_batch *b, const double *ll_host, const double *prior_h
 
 /* Launch plan the library would use for the main kernel on a batch with these maxima (no device needed):
  * out = {K positions per lane, D build (6 / 11 / 12), 1 if back-pointers go to HBM scratch else 0, waves per workgroup,
- *        read split of a haplotype, LDS bytes per workgroup, scratch bytes (low 31 bits, in KiB), waves per CU the plan expects}.
+ *        read split of a haplotype, LDS bytes per workgroup, scratch bytes (low 31 bits, in KiB), waves per CU the plan expects,
+ *        pairs per wavefront (1, or 2: the builds that run two reads side by side on 32-lane halves), 0}.
  * avg_reads = reads per window, n_haps = haplotypes the launch covers. */
-int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[8]);
+int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, int avg_reads, int n_haps, int32_t out[10]);
 
 /* name of the dominant kernel as rocprofv3 reports it, and launch geometry of the last launch */
 const char *dd_kernel_name(void);
 /* geometry of the last dd_launch_device on this host thread's library instance:
  * {K positions/lane, D build, waves/workgroup, LDS bytes/workgroup, grid, read split, LDS bytes/wave, shared LDS bytes} */
 void dd_last_launch(int32_t out[8]);
+/* Every main-model kernel launch of the last dd_launch_device / dd_compute_likelihoods call on this host thread (a ragged batch is one
+ * launch per non-empty (haplotype class, read class)): up to max_records records of DD_LAUNCH_LOG_FIELDS int32 each are written to out,
+ * the number of launches is returned.  Record: {K positions per lane, pairs per wavefront (1, or 2 on 32-lane halves), D build,
+ * 1 = back-pointers in HBM scratch, 1 = FOLD build, waves per workgroup, LDS bytes per workgroup, grid, read split, haplotypes covered,
+ * longest haplotype of the class, shortest admissible read, longest read of the class, waves per CU the plan expects, occupancy variant,
+ * duration in microseconds (-1 unless the process runs with DD_LAUNCH_TIMING=1: diagnostics, the read-out synchronises)}. */
+#define DD_LAUNCH_LOG_FIELDS 16
+int dd_launch_log(int32_t *out, int max_records);
 /* How many output arrays of the last dd_compute_likelihoods / _faster call on this host thread were written by the kernels directly
  * into the caller's memory: arrays that lie in page-locked, device-addressable host memory (dd_host_alloc, hipHostMalloc) are
  * not staged in HBM and not copied afterwards (status and offHapHMQ excepted).  0 for pageable memory. */

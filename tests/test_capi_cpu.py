@@ -163,17 +163,23 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert int(out[3]) == C.sizeof(capi.dd_batch)
 
 
-def test_launch_plan_rules(lib):
+def test_launch_plan_rules(lib, monkeypatch):
     """dd_plan_info (no device needed) pins the launch heuristics the GPU sweeps settled (profiles/r01/plan_check.jsonl,
     coverage_sweep.jsonl, batch_size_sweep.jsonl)."""
     def plan(mld=5, hap=120, L=100, reads=200, haps=80000):
         p = capi.params_cli_defaults(); p.maxLengthDel = mld
-        out = (C.c_int32 * 8)()
+        out = (C.c_int32 * 10)()
         assert lib.dd_plan_info(C.byref(p), hap, L, 1, reads, haps, C.byref(out)) == 0, capi.last_error()
-        return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7])
-    # lane tiling by haplotype length: numS = Hs+2 <= 64 K
-    assert [plan(hap=h)["K"] for h in (62, 63, 126, 127, 190, 191, 254, 255, 318, 319, 382, 383, 446, 447, 510, 511, 702, 703, 766)] == \
-        [1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 11, 12, 12]
+        return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7], G=out[8])
+    # lane tiling by haplotype length: numS = Hs+2 <= 64 K on a whole wavefront, or <= 32 K on a half (two pairs per wavefront, round 4)
+    # where that is the tighter fit: <= 30, <= 62, 63..94, 127..158, 191..222 bp
+    hs = (30, 31, 62, 63, 94, 95, 126, 127, 158, 159, 190, 191, 222, 223, 254, 255, 318, 319, 382, 383, 446, 447, 510, 511, 702, 703, 766)
+    assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in hs] == \
+        [(2, 1), (2, 2), (2, 2), (2, 3), (2, 3), (1, 2), (1, 2), (2, 5), (2, 5), (1, 3), (1, 3), (2, 7), (2, 7), (1, 4), (1, 4), (1, 5), (1, 5),
+         (1, 6), (1, 6), (1, 7), (1, 7), (1, 8), (1, 8), (1, 9), (1, 11), (1, 12), (1, 12)]
+    monkeypatch.setenv("DD_NO_HALF", "1")                      # A/B switch: whole-wavefront tilings only
+    assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in (30, 62, 63, 127, 191, 222)] == [(1, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 4)]
+    monkeypatch.delenv("DD_NO_HALF")
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6
@@ -190,7 +196,7 @@ def test_launch_plan_rules(lib):
     assert plan(haps=80000)["split"] == 1 and plan(haps=8)["split"] == 50 and plan(haps=512)["split"] == 10
     assert plan(haps=2048)["split"] == 3 and plan(haps=4096)["split"] == 2 and plan(haps=1024)["split"] == 5
     p = capi.params_cli_defaults()
-    out = (C.c_int32 * 8)()
+    out = (C.c_int32 * 10)()
     assert lib.dd_plan_info(C.byref(p), 767, 100, 1, 200, 8, C.byref(out)) == capi.DD_ERR_UNSUPPORTED
 
 
@@ -208,10 +214,10 @@ def test_length_classes_and_library_tables_on_the_host(lib):
     lst = np.zeros(pb.n_haps, np.int32)
     assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     hl = np.diff(pb.a["hap_seq_off"])
-    c = np.searchsorted([64 * k - 2 for k in range(1, 13)], hl, side="left")
-    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=12)).tolist()
+    c = np.searchsorted(capi.HAP_CLASS_BOUNDS, hl, side="left")             # one class per lane tiling (capi.cpp kHapClasses)
+    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=16)).tolist()
     assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    for k in range(12):
+    for k in range(16):
         seg = lst[cls.hap_class_off[k]:cls.hap_class_off[k + 1]]
         assert (c[seg] == k).all() and (np.diff(seg) > 0).all()
         assert cls.hap_class_max[k] == (int(hl[seg].max()) if len(seg) else 0)
@@ -244,8 +250,8 @@ def test_screen_windows_flags_only_the_offending_windows(lib):
     lst = np.zeros(pb.n_haps, np.int32)
     assert lib.dd_build_length_classes(C.byref(b), skip.ctypes.data_as(capi.c_u8p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    assert list(cls.hap_class_max) == [1, 100, 130] + [0] * 9            # class 0 holds the skipped haplotypes only
-    assert list(cls.hap_class_off) == [0, 4, 6] + [8] * 10
+    assert list(cls.hap_class_max) == [1, 0, 0, 100, 130] + [0] * 11     # class 0 holds the skipped haplotypes only
+    assert list(cls.hap_class_off) == [0, 4, 4, 4, 6] + [8] * 12
     assert cls.n_read_classes == 1 and cls.read_class_max[0] == 80
     assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == capi.DD_ERR_UNSUPPORTED
     pb2 = pack([limit, good])

@@ -340,10 +340,9 @@ def test_device_pointer_path_uses_length_classes(lib):
     dev = DeviceBatch(pb, p, "cuda:0")
     c = dev.classes
     hl = np.diff(pb.a["hap_seq_off"])
-    bounds = [64 * k - 2 for k in range(1, 13)]
-    cls = np.searchsorted(bounds, hl, side="left")
-    assert list(c.hap_class_off) == [0] + np.cumsum(np.bincount(cls, minlength=12)).tolist()
-    assert [int(x) for x in c.hap_class_max] == [int(hl[cls == k].max()) if (cls == k).any() else 0 for k in range(12)]
+    cls = np.searchsorted(capi.HAP_CLASS_BOUNDS, hl, side="left")
+    assert list(c.hap_class_off) == [0] + np.cumsum(np.bincount(cls, minlength=16)).tolist()
+    assert [int(x) for x in c.hap_class_max] == [int(hl[cls == k].max()) if (cls == k).any() else 0 for k in range(16)]
     rl = np.diff(pb.a["read_seq_off"])
     assert c.n_read_classes == 2 and list(c.read_class_max) == [int(rl[rl <= 160].max()), int(rl.max())]
     dev.launch()

@@ -31,10 +31,13 @@ def time_point(pb, p):
     return best, ("hbm" if g["D"] >= 100 else "lds"), g["K"]
 
 
+# haplotype lengths: every lane tiling near full (43 ... 763 after the variants' indels) and, since round 4, the lengths between
+# the tilings' steps (62 / 126 / 190 bp), where real windows sit
+HAPS = (40, 62, 77, 97, 120, 124, 127, 137, 147, 157, 180, 192, 197, 250, 380, 500, 760) if "--full" in sys.argv else (40, 120, 180, 250, 380, 500, 760)
 bad = 0
 for mld in (5, 10):
     for L in (36, 76, 100, 110, 120, 130, 140, 150, 250, 400, 700, 1000):
-        for hap in (40, 120, 180, 250, 380, 500, 760):
+        for hap in HAPS:
             pairs_target = 2.5e5 * (100 * 120) / (L * hap)
             R = 100
             n = max(2, int(pairs_target / (4 * R)))
