@@ -218,14 +218,14 @@ def ragged_leg(params, device, windows=2400, steps=3):
         rw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_read_off"]))
         launches = []
         for rec in log:
-            lo_h = max([0] + [q["max_hap"] for q in log if q["max_hap"] < rec["max_hap"]])
-            hsel = (hl > lo_h) & (hl <= rec["max_hap"])
+            ci = int(np.searchsorted(capi.HAP_CLASS_BOUNDS, rec["max_hap"], side="left"))    # the launch's lane tiling = haplotype-length class
+            hsel = (hl > (capi.HAP_CLASS_BOUNDS[ci - 1] if ci else 0)) & (hl <= capi.HAP_CLASS_BOUNDS[ci])
             rsel = (rl >= rec["min_read"]) & (rl <= rec["max_read"])
             rsum = np.bincount(rw[rsel], weights=rl[rsel], minlength=pb.n_windows)
             cells = float((hl[hsel] * rsum[hw[hsel]]).sum())
             pos = 64 * rec["K"] // rec["pairs_per_wave"]
             launches.append({"K": rec["K"], "pairs_per_wave": rec["pairs_per_wave"], "D": rec["D"], "bt": "hbm" if rec["gbt"] else "lds", "fold": bool(rec["fold"]),
-                             "haplotypes": int(hsel.sum()), "hap_len": [int(hl[hsel].min()), int(hl[hsel].max())] if hsel.any() else None,
+                             "haplotypes": rec["n_haps"], "waves": rec["waves"], "read_split": rec["split"], "hap_len": [int(hl[hsel].min()), int(hl[hsel].max())] if hsel.any() else None,
                              "read_len": [rec["min_read"], rec["max_read"]], "share_of_cells": cells / pb.cells,
                              "lane_utilisation": float((hl[hsel] + 2).mean() / pos) if hsel.any() else None,
                              "ms": rec["us"] / 1e3 if rec["us"] >= 0 else None})

@@ -88,7 +88,7 @@ class dd_sizes(C.Structure):
 
 class dd_device_batch(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_haps", C.c_int32), ("n_reads", C.c_int32),
-                ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32),
+                ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32), ("max_window_reads", C.c_int32),
                 ("win_hap_off", C.c_void_p), ("win_read_off", C.c_void_p), ("win_hap_start", C.c_void_p),
                 ("hap_seq_off", C.c_void_p), ("hap_seq", C.c_void_p), ("hap_var_off", C.c_void_p), ("hap_var", C.c_void_p),
                 ("read_seq_off", C.c_void_p), ("read_seq", C.c_void_p), ("read_qidx", C.c_void_p), ("read_mqidx", C.c_void_p),
@@ -102,14 +102,21 @@ class dd_device_batch(C.Structure):
 
 
 # haplotype-length classes of a ragged batch, one per lane tiling (capi.cpp kHapClasses): longest haplotype, pairs per wavefront, positions per lane
-HAP_CLASSES = [(30, 2, 1), (62, 2, 2), (94, 2, 3), (126, 1, 2), (158, 2, 5), (190, 1, 3), (222, 2, 7), (254, 1, 4), (318, 1, 5), (382, 1, 6),
+HAP_CLASSES = [(30, 2, 1), (62, 1, 1), (94, 2, 3), (126, 1, 2), (158, 2, 5), (190, 1, 3), (222, 2, 7), (254, 1, 4), (318, 1, 5), (382, 1, 6),
                (446, 1, 7), (510, 1, 8), (574, 1, 9), (638, 1, 10), (702, 1, 11), (766, 1, 12)]
 HAP_CLASS_BOUNDS = [c[0] for c in HAP_CLASSES]
 
 
+N_HAP_CLASSES, N_READ_CLASSES = 16, 3
+
+
+class dd_launch_class(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("list_off", "list_len", "hap_class", "max_hap_len", "min_read_len", "max_read_len",
+                                         "max_window_reads", "avg_window_reads")]
+
+
 class dd_length_classes(C.Structure):
-    _fields_ = [("hap_class_off", C.c_int32 * 17), ("hap_class_max", C.c_int32 * 16), ("n_read_classes", C.c_int32),
-                ("read_class_lo", C.c_int32 * 2), ("read_class_max", C.c_int32 * 2)]
+    _fields_ = [("n_launches", C.c_int32), ("list_len", C.c_int32), ("launch", dd_launch_class * (N_HAP_CLASSES * N_READ_CLASSES))]
 
 
 class dd_device_result(C.Structure):
@@ -161,7 +168,7 @@ def load():
     lib.dd_build_tables.argtypes = [C.POINTER(dd_params), c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]
     lib.dd_build_symbol_lut.argtypes = [C.POINTER(dd_batch), C.POINTER(C.c_uint8)]
     lib.dd_build_library_tables.argtypes = [C.POINTER(dd_batch), c_f64p, c_f64p]
-    lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_u8p, c_i32p, C.POINTER(dd_length_classes)]
+    lib.dd_build_length_classes.argtypes = [C.POINTER(dd_batch), c_u8p, C.POINTER(dd_params), c_i32p, C.POINTER(dd_length_classes)]
     lib.dd_screen_windows.argtypes = [C.POINTER(dd_batch), c_u8p, C.POINTER(C.c_int32 * 2)]
     lib.dd_plan_info.argtypes = [C.POINTER(dd_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32 * 10)]
     lib.dd_build_index.argtypes = [C.POINTER(dd_batch), c_i32p, c_i64p, c_i64p, c_i64p]

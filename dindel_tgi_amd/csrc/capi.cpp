@@ -50,11 +50,13 @@ double hp_error(int hpLen)
 // Lane tilings, by haplotype length.  numS = Hs + 2 states go over the 64 lanes of a wavefront, K positions per lane (every K = 1..12 is
 // instantiated, so no shape pays for more than 63 positions it does not have) — or, round 4, over the 32 lanes of HALF a wavefront, two
 // pairs side by side (G = 2), where 32 K is the tighter fit: 127..158 bp run as K = 5 halves (2.5 lane-positions per pair instead of 3),
-// 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves (3.5 instead of 4), and <= 62 bp as K = 2 / 1 halves (the same
-// positions as K = 1 on a whole wavefront, but a lane's second position comes from its own registers instead of the LDS exchange).
+// 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves (3.5 instead of 4), <= 30 bp as K = 1 halves (0.5 instead of 1).
+// Measured against the whole-wavefront tilings (tools/tiling_sweep.py, profiles/r04/tiling_sweep*.jsonl; 8 x 200 reads of 100 bp): <= 30 bp
+// x 1.8, 63..94 bp + 2-4 %, 127..158 bp + 14-16 %, 191..222 bp + 9-11 %; 31..62 bp as K = 2 halves were level with K = 1 on a whole
+// wavefront (its FOLD build), so that class stays there.
 struct HapClassDef { int bound, G, K; };     // haplotypes up to `bound` bp: G pairs per wavefront, K positions per lane
 const HapClassDef kHapClasses[DD_N_HAP_CLASSES] = {
-    {30, 2, 1}, {62, 2, 2}, {94, 2, 3}, {126, 1, 2}, {158, 2, 5}, {190, 1, 3}, {222, 2, 7}, {254, 1, 4},
+    {30, 2, 1}, {62, 1, 1}, {94, 2, 3}, {126, 1, 2}, {158, 2, 5}, {190, 1, 3}, {222, 2, 7}, {254, 1, 4},
     {318, 1, 5}, {382, 1, 6}, {446, 1, 7}, {510, 1, 8}, {574, 1, 9}, {638, 1, 10}, {702, 1, 11}, {DD_MAX_HAP_LEN, 1, 12}};
 bool half_wave_off() { return getenv("DD_NO_HALF") != nullptr; }   // A/B and tests: whole-wavefront tilings only
 int hap_class_of(int hap_len)
@@ -97,7 +99,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
     A.lds_off_Q = o;  o += up16((uint32_t)n_qual * 32);
     A.n_qual = n_qual;
     A.lds_off_C = o;  A.lds_off_Y = o;
-    if (gbt && (Dt > 7 || K >= 3)) {             // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
+    if ((gbt || G > 1) && (Dt > 7 || K >= 3)) {  // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
         o += up16((uint32_t)K * Dt * W * 8u);
         A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
     }
@@ -139,6 +141,13 @@ uint32_t bt_word_bytes(int K, int Dt)
 {
     const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
     return bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+}
+
+// bytes of one wavefront's region of the HBM scratch: its back-pointer tile + (K >= 3 or half-wave builds) the [2 K][64] doubles where
+// beta[bMid] waits for the join (hmm_kernel.hip STASH)
+size_t scratch_wave_bytes(int K, int Dt, int G, int max_read_len)
+{
+    return (size_t)max_read_len * 64u * bt_word_bytes(K, Dt) + ((K >= 3 || G > 1) ? (size_t)2 * K * 64 * 8 : 0);
 }
 
 // Launch plan: LDS-resident back-pointers when that keeps the CU as full as the registers allow, otherwise
@@ -209,7 +218,7 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     if (pl.gbt) {
         const int blocks_per_cu = (pl.waves_per_cu + pl.waves - 1) / pl.waves;
         pl.grid_cap = 256u * (unsigned)blocks_per_cu;
-        pl.scratch_bytes = (size_t)pl.grid_cap * pl.waves * (size_t)max_read_len * 64u * bt_word_bytes(pl.K, pl.Dt);
+        pl.scratch_bytes = (size_t)pl.grid_cap * pl.waves * scratch_wave_bytes(pl.K, pl.Dt, pl.G, max_read_len);
     }
     return DD_SUCCESS;
 }
@@ -664,53 +673,133 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
     return T_END;
 }
 
-static const int kReadClassBounds[2] = {160, DD_MAX_READ_LEN};
-
-int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out)
+// ---- launch classes of a ragged batch ----
+// A launch = (lane tiling of the haplotypes, read-length interval).  The read intervals of a tiling are cut where its launch plan
+// changes: [1, T] while the back-pointer tile still fits LDS at full occupancy (T from make_plan: ~115 bp at K = 2), (T, 160], (160, 1024]
+// — so short reads keep the faster LDS build when a batch also holds long ones (round 3 had one "<= 160 bp" class: a batch with 150-bp
+// reads put its 100-bp reads on the scratch build, 18 % slower).  A haplotype is listed in a launch only if its window holds a read of the
+// interval: the other launches do not repeat its set-up.
+static int lds_read_threshold(const dd_params *p, int max_hap_len, int n_qual)
 {
-    if (!b || !hap_class_list || !out) return fail(DD_ERR_INVALID, "null argument");
+    if (!p || check_params(p) != DD_SUCCESS) return 0;
+    int lo = 0, hi = 160;                       // largest L in [1, 160] whose plan keeps the back-pointers in LDS (0: none)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        Plan pl;
+        ddk::KernelArgs A;
+        memset(&A, 0, sizeof(A));
+        if (make_plan(p, max_hap_len, mid, n_qual > 0 ? n_qual : 1, pl, A) == DD_SUCCESS && !pl.gbt) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, const dd_params *p, int32_t *list, dd_length_classes *out)
+{
     dd_sizes sz;
     int rc = dd_batch_sizes(b, &sz);
     if (rc) return rc;
     memset(out, 0, sizeof(*out));
-    std::vector<int> cls((size_t)sz.n_haps);
-    int count[DD_N_HAP_CLASSES] = {0};
-    for (int w = 0; w < b->n_windows; w++) {
-        const bool skip = win_skip && win_skip[w];
+    const int W = b->n_windows;
+    // pass 1: haplotype class maxima (the read thresholds depend on the class' longest haplotype)
+    int hmax[DD_N_HAP_CLASSES] = {0};
+    bool any_skipped = false;
+    for (int w = 0; w < W; w++) {
+        if (win_skip && win_skip[w]) { any_skipped = any_skipped || b->win_hap_off[w + 1] > b->win_hap_off[w]; continue; }
         for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
             const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
-            int c = 0;
-            if (!skip) {
-                if (len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766 in a window that is not flagged in win_skip");
-                c = hap_class_of(len);
-                if (len > out->hap_class_max[c]) out->hap_class_max[c] = len;
-            }
-            cls[(size_t)h] = c;              // haplotypes of skipped windows ride in class 0: the kernel only marks their pairs
-            count[c]++;
+            if (len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766 in a window that is not flagged in win_skip");
+            const int c = hap_class_of(len < 1 ? 1 : len);
+            if (len > hmax[c]) hmax[c] = len;
         }
     }
-    if (count[0] > 0 && out->hap_class_max[0] == 0) out->hap_class_max[0] = 1;   // class 0 holds skipped haplotypes only: still launched
-    for (int c = 0; c < DD_N_HAP_CLASSES; c++) out->hap_class_off[c + 1] = out->hap_class_off[c] + count[c];
-    int fill[DD_N_HAP_CLASSES];
-    for (int c = 0; c < DD_N_HAP_CLASSES; c++) fill[c] = out->hap_class_off[c];
-    for (int64_t h = 0; h < sz.n_haps; h++) hap_class_list[fill[cls[(size_t)h]]++] = (int32_t)h;
-    int lo = 1;
-    for (int k = 0; k < 2; k++) {
-        int mx = 0;
-        for (int w = 0; w < b->n_windows; w++) {
-            if (win_skip && win_skip[w]) continue;
-            for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
+    int bound[DD_N_HAP_CLASSES][DD_N_READ_CLASSES];          // upper read length of each interval of each tiling
+    const bool one_read_class = getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k");   // A/B: haplotype classes only
+    for (int c = 0; c < DD_N_HAP_CLASSES; c++) {
+        int T = hmax[c] > 0 ? lds_read_threshold(p, hmax[c], b->n_qual) : 0;
+        if (getenv("DD_READ_BOUND")) T = atoi(getenv("DD_READ_BOUND"));                                    // A/B only
+        if (T < 1 || T >= 160) T = 0;
+        bound[c][0] = one_read_class ? DD_MAX_READ_LEN : (T ? T : 160);
+        bound[c][1] = one_read_class ? DD_MAX_READ_LEN : 160;
+        bound[c][2] = DD_MAX_READ_LEN;
+    }
+    auto read_class = [&](int c, int len) { return len <= bound[c][0] ? 0 : (len <= bound[c][1] ? 1 : 2); };
+    // pass 2: per window, which (tiling, interval) launches its haplotypes take part in
+    struct Acc { std::vector<int32_t> haps; int max_hap = 0, max_read = 0, max_reads = 0; int64_t sum_reads = 0, n_win = 0; };
+    std::vector<Acc> acc((size_t)DD_N_HAP_CLASSES * DD_N_READ_CLASSES);
+    std::vector<int32_t> skipped;                             // haplotypes of skipped windows: marked by the first launch
+    for (int w = 0; w < W; w++) {
+        const int64_t h0 = b->win_hap_off[w], h1 = b->win_hap_off[w + 1], q0 = b->win_read_off[w], q1 = b->win_read_off[w + 1];
+        if (win_skip && win_skip[w]) { for (int64_t h = h0; h < h1; h++) skipped.push_back((int32_t)h); continue; }
+        if (h1 <= h0 || q1 <= q0) continue;
+        unsigned seen = 0;                                    // tilings of this window already handled
+        for (int64_t h = h0; h < h1; h++) {
+            const int hl = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+            const int c = hap_class_of(hl < 1 ? 1 : hl);
+            if (seen & (1u << c)) continue;
+            seen |= 1u << c;
+            int cnt[DD_N_READ_CLASSES] = {0}, mx[DD_N_READ_CLASSES] = {0};
+            for (int64_t q = q0; q < q1; q++) {
                 const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
-                if (len >= lo && len <= kReadClassBounds[k] && len > mx) mx = len;
+                if (len < 1) continue;
+                const int k = read_class(c, len);
+                cnt[k]++;
+                if (len > mx[k]) mx[k] = len;
+            }
+            for (int k = 0; k < DD_N_READ_CLASSES; k++) {
+                if (!cnt[k]) continue;
+                Acc &a = acc[(size_t)c * DD_N_READ_CLASSES + k];
+                for (int64_t g = h; g < h1; g++) {
+                    const int gl = b->hap_seq_off[g + 1] - b->hap_seq_off[g];
+                    if (hap_class_of(gl < 1 ? 1 : gl) != c) continue;
+                    a.haps.push_back((int32_t)g);
+                    if (gl > a.max_hap) a.max_hap = gl;
+                }
+                if (mx[k] > a.max_read) a.max_read = mx[k];
+                if (cnt[k] > a.max_reads) a.max_reads = cnt[k];
+                a.sum_reads += cnt[k];
+                a.n_win++;
             }
         }
-        if (mx) { out->read_class_lo[out->n_read_classes] = lo; out->read_class_max[out->n_read_classes] = mx; out->n_read_classes++; }
-        lo = kReadClassBounds[k] + 1;
     }
-    if (out->n_read_classes == 0 && sz.n_reads > 0) {   // every window skipped: one (dummy) read class so that the marking launch happens
-        out->read_class_lo[0] = 1; out->read_class_max[0] = 1; out->n_read_classes = 1;
+    int32_t off = 0;
+    auto emit = [&](int c, int k, Acc &a, const std::vector<int32_t> *extra) {
+        dd_launch_class &L = out->launch[out->n_launches++];
+        L.list_off = off;
+        if (extra && !extra->empty()) {                        // merge (both ascending) so that the list stays sorted
+            std::vector<int32_t> m(a.haps.size() + extra->size());
+            std::merge(a.haps.begin(), a.haps.end(), extra->begin(), extra->end(), m.begin());
+            a.haps.swap(m);
+        }
+        L.list_len = (int32_t)a.haps.size();
+        if (list) memcpy(list + off, a.haps.data(), a.haps.size() * sizeof(int32_t));
+        off += L.list_len;
+        L.hap_class = c;
+        L.max_hap_len = a.max_hap > 0 ? a.max_hap : 1;
+        L.min_read_len = k == 0 ? 1 : bound[c][k - 1] + 1;
+        L.max_read_len = a.max_read > 0 ? a.max_read : 1;
+        L.max_window_reads = a.max_reads;
+        L.avg_window_reads = a.n_win ? (int32_t)((a.sum_reads + a.n_win - 1) / a.n_win) : 0;
+    };
+    bool first = true;
+    for (int c = 0; c < DD_N_HAP_CLASSES; c++)
+        for (int k = 0; k < DD_N_READ_CLASSES; k++) {
+            Acc &a = acc[(size_t)c * DD_N_READ_CLASSES + k];
+            if (a.haps.empty()) continue;
+            emit(c, k, a, first ? &skipped : nullptr);
+            first = false;
+        }
+    if (first && !skipped.empty()) {                           // nothing but skipped windows: one launch that only marks their pairs
+        Acc a;
+        emit(0, 0, a, &skipped);
     }
+    out->list_len = off;
     return DD_SUCCESS;
+}
+
+int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, const dd_params *p, int32_t *hap_class_list, dd_length_classes *out)
+{
+    if (!b || !hap_class_list || !out) return fail(DD_ERR_INVALID, "null argument");
+    return build_launch_classes(b, win_skip, p, hap_class_list, out);
 }
 
 size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
@@ -722,15 +811,14 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
     memset(&A, 0, sizeof(A));
     if (make_plan(p, b->max_hap_len, b->max_read_len, b->n_qual, pl, A) != DD_SUCCESS) return 0;
     size_t bytes = pl.scratch_bytes;
-    if (b->classes && b->hap_class_list)          // per-class launches: the largest scratch any (haplotype, read) class needs
-        for (int c = 0; c < DD_N_HAP_CLASSES; c++)
-            for (int k = 0; k < b->classes->n_read_classes && b->classes->hap_class_max[c] > 0; k++) {
-                ddk::KernelArgs A2;
-                memset(&A2, 0, sizeof(A2));
-                if (make_plan(p, b->classes->hap_class_max[c], b->classes->read_class_max[k], b->n_qual, pl, A2) == DD_SUCCESS &&
-                    pl.scratch_bytes > bytes)
-                    bytes = pl.scratch_bytes;
-            }
+    if (b->classes && b->hap_class_list)          // per-class launches: the largest scratch any of them needs
+        for (int i = 0; i < b->classes->n_launches; i++) {
+            ddk::KernelArgs A2;
+            memset(&A2, 0, sizeof(A2));
+            if (make_plan(p, b->classes->launch[i].max_hap_len, b->classes->launch[i].max_read_len, b->n_qual, pl, A2) == DD_SUCCESS &&
+                pl.scratch_bytes > bytes)
+                bytes = pl.scratch_bytes;
+        }
     return bytes;
 }
 
@@ -742,6 +830,7 @@ struct LenClass {
     const int32_t *hap_list = nullptr;   // device: haplotype indices of the class (sorted); nullptr = all haplotypes
     int list_begin = 0, list_end = 0;    // range of hap_list this launch covers
     int max_hap_len = 0, max_read_len = 0, min_read_len = 1;
+    int max_window_reads = 0, avg_window_reads = 0;   // reads of the class per window of the list (0 = not known)
     bool run_onhap = true;
 };
 
@@ -943,7 +1032,7 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     size_t lds = pl.lds;
     // thin windows: a wavefront works on one read at a time, so a workgroup never needs more waves than the windows have
     // reads (tools/coverage_sweep.py: 2 reads per window ran at half the rate with idle waves in every workgroup)
-    const int64_t avg_reads_w = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    const int64_t avg_reads_w = (lc && lc->avg_window_reads > 0) ? lc->avg_window_reads : (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
     {
         const int w2 = waves_for_reads((avg_reads_w + pl.G - 1) / pl.G, waves, pl.waves_per_cu);   // a wavefront takes G reads at a time
         if (w2 != waves) {
@@ -956,11 +1045,12 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
             return fail(DD_ERR_INVALID, "workspace too small for this shape: allocate dd_workspace_bytes() bytes");
         A.bt_scratch = workspace;
         A.bt_rows = cls_read;
+        A.bt_wave_bytes = (uint32_t)scratch_wave_bytes(K, Dt, pl.G, cls_read);
     }
     // enough workgroups to fill 256 CUs several times over, but keep >= 1 read per wave
     int64_t target_blocks = 4096;
     if (const char *e = getenv("DD_TARGET_BLOCKS")) { const long v = atol(e); if (v >= 1) target_blocks = v; }   // A/B only
-    int64_t avg_reads = (b->n_reads + b->n_windows - 1) / (b->n_windows > 0 ? b->n_windows : 1);
+    int64_t avg_reads = avg_reads_w;
     if (hap_end < 0) { hap_begin = 0; hap_end = b->n_haps; read_begin = 0; read_end = b->n_reads; }
     if (lc && lc->hap_list) { hap_begin = lc->list_begin; hap_end = lc->list_end; }   // positions in the class list
     // the split is chosen for the haplotypes THIS launch covers: a rare length class or a small window block must still
@@ -968,7 +1058,23 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     // workgroups the chip holds at once (one-shot grids; a persistent GBT grid is capped to that number below anyway)
     int64_t resident = 256 * (int64_t)std::max(1, std::min((int)((160u * 1024u) / (lds ? lds : 1)), pl.waves_per_cu / waves));
     if (getenv("DD_SPLIT_NO_ROUNDS")) resident = 0;                            // A/B only: the rule before round 3
-    const int64_t split = pick_split(hap_end - hap_begin, (avg_reads + pl.G - 1) / pl.G, waves, target_blocks, resident);
+    int64_t split = pick_split(hap_end - hap_begin, (avg_reads + pl.G - 1) / pl.G, waves, target_blocks, resident);
+    // Ragged windows: `split` suits a window with the average number of reads; a haplotype whose window has more gets proportionally more
+    // workgroups (the kernel derives its own count from reads_per_wave), so that a 400-read window among 100-read ones does not end the
+    // launch with one workgroup still at work; when the spread is wide the work of a wavefront is also capped (DD_READS_PER_WAVE, A/B).
+    A.reads_per_wave = 0;
+    const int max_reads = (lc && lc->max_window_reads > 0) ? lc->max_window_reads : b->max_window_reads;
+    if (max_reads > 0 && max_reads * 4 > avg_reads * 5 && !getenv("DD_UNIFORM_SPLIT")) {
+        const int64_t units = (avg_reads + pl.G - 1) / pl.G, max_units = (max_reads + pl.G - 1) / pl.G;
+        int64_t rpw = (units + waves * split - 1) / (waves * split);
+        int cap_rpw = (Dt > 7 || K >= 3) ? 24 : 12;
+        if (const char *e = getenv("DD_READS_PER_WAVE")) { const int v = atoi(e); if (v >= 1) cap_rpw = v; }
+        if (rpw > cap_rpw) rpw = cap_rpw;
+        if (rpw < 1) rpw = 1;
+        A.reads_per_wave = (int32_t)rpw;
+        split = (max_units + waves * rpw - 1) / (waves * rpw);
+        if (split < 1) split = 1;
+    }
     A.n_split = (int32_t)split;
     if ((int64_t)b->n_haps * split > 0x7fffffffLL) return fail(DD_ERR_UNSUPPORTED, "batch too large for one launch");
     A.item_begin = (int32_t)(hap_begin * split);
@@ -1038,30 +1144,25 @@ int dd_plan_info(const dd_params *p, int max_hap_len, int max_read_len, int n_qu
 int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_result *r, void *workspace, size_t workspace_bytes, void *stream)
 {
     launch_log_clear();
-    if (b && b->classes && b->hap_class_list) {
-        // ragged batch: one launch per non-empty (haplotype class, read class), onHap once at the end
+    if (b && b->classes && b->hap_class_list && b->classes->n_launches > 1) {
+        // ragged batch: one launch per (lane tiling, read-length interval) that has work, onHap once at the end
         const dd_length_classes *C = b->classes;
-        int total = 0, launched = 0;
-        for (int c = 0; c < DD_N_HAP_CLASSES; c++)
-            if (C->hap_class_off[c + 1] > C->hap_class_off[c]) total += C->n_read_classes;
-        if (total > 1) {
-            for (int c = 0; c < DD_N_HAP_CLASSES; c++) {
-                if (C->hap_class_off[c + 1] <= C->hap_class_off[c]) continue;
-                LenClass lc;
-                lc.hap_list = b->hap_class_list;
-                lc.list_begin = C->hap_class_off[c];
-                lc.list_end = C->hap_class_off[c + 1];
-                lc.max_hap_len = C->hap_class_max[c];
-                for (int k = 0; k < C->n_read_classes; k++) {
-                    lc.min_read_len = C->read_class_lo[k];
-                    lc.max_read_len = C->read_class_max[k];
-                    lc.run_onhap = (++launched == total);
-                    const int rc = launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, b->n_haps, 0, b->n_reads, &lc);
-                    if (rc) return rc;
-                }
-            }
-            return DD_SUCCESS;
+        for (int i = 0; i < C->n_launches; i++) {
+            const dd_launch_class &L = C->launch[i];
+            LenClass lc;
+            lc.hap_list = b->hap_class_list + L.list_off;
+            lc.list_begin = 0;
+            lc.list_end = L.list_len;
+            lc.max_hap_len = L.max_hap_len;
+            lc.min_read_len = L.min_read_len;
+            lc.max_read_len = L.max_read_len;
+            lc.max_window_reads = L.max_window_reads;
+            lc.avg_window_reads = L.avg_window_reads;
+            lc.run_onhap = (i == C->n_launches - 1);
+            const int rc = launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, b->n_haps, 0, b->n_reads, &lc);
+            if (rc) return rc;
         }
+        return DD_SUCCESS;
     }
     return launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, -1, 0, 0);
 }
@@ -1320,72 +1421,33 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     rc = dd_build_tables(p, b->qual_table, b->n_qual, b->mapq_table, b->n_mapq, tables.data());
     if (rc < 0) return rc;
 
-    // ---- host-side planning first (no device work yet): length classes and scratch size ----
-    // Ragged batches: haplotypes are grouped by the lane tiling they need (K) and reads by length class, and each
-    // non-empty (K class, length class) gets its own launches — a single 170-bp haplotype or 250-bp read no longer
-    // drags every pair of the batch onto the K=3 / long-read build.
-    // reads: one class up to 160 bp (LDS back-pointer tile still leaves >= 8 waves per CU), one for longer reads
-    // (HBM-scratch build).  Finer read classes cost more in repeated per-haplotype setup than they gain
-    // (tools/ragged_bench.py: 5000 ragged windows 0.2125 s with haplotype classes only, 0.2532 s with five read classes,
-    // 0.2455 s with one batch-wide plan).
-    int kReadBounds[] = {kReadClassBounds[0], kReadClassBounds[1]};
-    if (const char *e = getenv("DD_READ_BOUND")) { const int v = atoi(e); if (v >= 1 && v < DD_MAX_READ_LEN) kReadBounds[0] = v; }   // A/B only
-    struct HostClass { std::vector<int32_t> haps; int max_hap = 0; const int32_t *dev = nullptr; };
-    std::vector<HostClass> hcls(DD_N_HAP_CLASSES);
-    for (int w = 0; w < W; w++)
-        for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
-            const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
-            size_t c = 0;
-            if (!win_skip[(size_t)w]) {          // haplotypes of skipped windows ride in class 0 (their pairs are only marked)
-                c = (size_t)hap_class_of(len);
-                if (len > hcls[c].max_hap) hcls[c].max_hap = len;
-            }
-            hcls[c].haps.push_back((int32_t)h);
-        }
-    if (!hcls[0].haps.empty() && hcls[0].max_hap == 0) hcls[0].max_hap = 1;
-    struct ReadClass { int lo, hi, max_len; };
-    std::vector<ReadClass> rcls;
-    {
-        int mx[2] = {0, 0};                                  // longest read of each class, one pass over the reads
-        for (int w = 0; w < W; w++) {
-            if (win_skip[(size_t)w]) continue;
-            for (int64_t q = b->win_read_off[w]; q < b->win_read_off[w + 1]; q++) {
-                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
-                if (len < 1) continue;
-                const int c = len <= kReadBounds[0] ? 0 : 1;
-                if (len <= kReadBounds[c] && len > mx[c]) mx[c] = len;
-            }
-        }
-        int lo = 1;
-        for (int c = 0; c < 2; c++) {
-            if (mx[c]) rcls.push_back({lo, kReadBounds[c], mx[c]});
-            lo = kReadBounds[c] + 1;
-        }
-        if (rcls.empty()) rcls.push_back({1, kReadBounds[0], 1});       // every window skipped: the marking launch still runs
-        if (getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k") && !rcls.empty()) {
-            ReadClass all = {1, DD_MAX_READ_LEN, rcls.back().max_len};      // A/B: haplotype classes only
-            rcls.assign(1, all);
-        }
+    // ---- host-side planning first (no device work yet): launch classes and scratch size ----
+    // Ragged batches: one launch per (lane tiling of the haplotypes, read-length interval) that has work (build_launch_classes) — a single
+    // 170-bp haplotype or 250-bp read does not drag every pair of the batch onto the K = 3 / long-read build.
+    dd_length_classes lcls;
+    std::vector<int32_t> class_list;
+    memset(&lcls, 0, sizeof(lcls));
+    if (model == MODEL_FBMAXERR && !getenv("DD_NO_LENGTH_CLASSES")) {                      // env: A/B only
+        class_list.resize((size_t)sz.n_haps * DD_N_READ_CLASSES + 1);
+        if ((rc = build_launch_classes(b, n_skip ? win_skip.data() : nullptr, p, class_list.data(), &lcls))) return rc;
     }
+    const int32_t *class_list_dev = nullptr;
     dd_device_batch db;
     memset(&db, 0, sizeof(db));
     db.n_windows = W; db.n_haps = (int32_t)sz.n_haps; db.n_reads = (int32_t)sz.n_reads;
     db.max_hap_len = sz.max_hap_len; db.max_read_len = sz.max_read_len;
     db.n_qual = b->n_qual; db.n_mapq = b->n_mapq;
+    for (int w = 0; w < W; w++)
+        if (!win_skip[(size_t)w] && b->win_read_off[w + 1] - b->win_read_off[w] > db.max_window_reads) db.max_window_reads = b->win_read_off[w + 1] - b->win_read_off[w];
     size_t ws_bytes = model == MODEL_S ? 0 : dd_workspace_bytes(p, &db);
-    int n_classes = 0;
-    for (auto &hc : hcls) {
-        if (hc.haps.empty()) continue;
-        n_classes++;
-        if (model == MODEL_S) continue;
-        for (auto &rcl : rcls) {
-            dd_device_batch tmp = db;
-            tmp.max_hap_len = hc.max_hap; tmp.max_read_len = rcl.max_len;
-            const size_t w = dd_workspace_bytes(p, &tmp);
-            if (w > ws_bytes) ws_bytes = w;
-        }
+    const bool single_class = lcls.n_launches <= 1;
+    if (!single_class) {
+        db.classes = &lcls;
+        db.hap_class_list = class_list.data();             // (host pointer: only dd_workspace_bytes' class walk looks at it here)
+        const size_t w2 = dd_workspace_bytes(p, &db);
+        if (w2 > ws_bytes) ws_bytes = w2;
+        db.classes = nullptr; db.hap_class_list = nullptr;
     }
-    const bool single_class = model == MODEL_S || (n_classes == 1 && rcls.size() == 1) || getenv("DD_NO_LENGTH_CLASSES") != nullptr;   // env: A/B only
 
     clk.mark("plan");
     // ---- device arena (cached per host thread) ----
@@ -1393,7 +1455,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
     const size_t n_var = b->hap_var_off ? (size_t)b->hap_var_off[sz.n_haps] : 0;
     const size_t in_bytes = (size_t)(W + 1) * (4 + 4 + 8 + 8 + 8) + (size_t)W * 4 + (size_t)(sz.n_haps + 1) * 8 + (size_t)sz.hap_bases +
                             (size_t)(sz.n_reads + 1) * 4 + (size_t)sz.read_bases * 2 + (size_t)sz.n_reads * 6 + n_var * 20 +
-                            (size_t)sz.n_haps * 8 + DD_TABLE_DOUBLES * 8 + 48 * 256 + (size_t)W + 256 +
+                            (size_t)sz.n_haps * 4 + (size_t)lcls.list_len * 4 + 64 + DD_TABLE_DOUBLES * 8 + 48 * 256 + (size_t)W + 256 +
                             (lib_log95.empty() ? 0 : (size_t)sz.n_reads * 9 + (lib_logprob.size() + lib_log95.size()) * 8 + (size_t)(b->n_libs + 1) * 4);
     const size_t out_bytes = np * (4 * 8 + 2 + 8 * 2 + 4) + (size_t)sz.hpos_len * 2 + 2 * (size_t)sz.var_cov_len + (size_t)sz.n_reads + 24 * 256;
     const bool staged = in_bytes + out_bytes <= (size_t)64 << 20;    // small batch: one H2D, one D2H through the pinned mirror
@@ -1457,9 +1519,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
         if ((rc = dev.upload(&db.lib_logprob, (const double *)lib_logprob.data(), lib_logprob.size()))) return rc;
         if ((rc = dev.upload(&db.lib_log95, (const double *)lib_log95.data(), lib_log95.size()))) return rc;
     }
-    if (!single_class)
-        for (auto &hc : hcls)
-            if (!hc.haps.empty() && (rc = dev.upload(&hc.dev, (const int32_t *)hc.haps.data(), hc.haps.size()))) return rc;
+    if (!single_class && (rc = dev.upload(&class_list_dev, (const int32_t *)class_list.data(), (size_t)lcls.list_len))) return rc;
     if ((rc = dev.flush_uploads(ctx.s[0]))) return rc;       // staged mode: the one H2D copy
     if (!staged) HIP_TRY(hipStreamSynchronize(nullptr));     // pageable uploads went through the null stream's DMA
     clk.mark("upload");
@@ -1551,22 +1611,20 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
             rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1);
             if (rc) return rc;
         } else {
-            // every (K class, length class) of this window block, then onHap once
-            int launched = 0, total = 0;
-            for (auto &hc : hcls) if (!hc.haps.empty()) total += (int)rcls.size();
-            for (auto &hc : hcls) {
-                if (hc.haps.empty()) continue;
+            // every launch class of this window block, then onHap once
+            for (int i = 0; i < lcls.n_launches; i++) {
+                const dd_launch_class &L = lcls.launch[i];
+                const int32_t *hl = class_list.data() + L.list_off;
                 LenClass lc;
-                lc.hap_list = hc.dev;
-                lc.list_begin = (int)(std::lower_bound(hc.haps.begin(), hc.haps.end(), g0) - hc.haps.begin());
-                lc.list_end = (int)(std::lower_bound(hc.haps.begin(), hc.haps.end(), g1) - hc.haps.begin());
-                lc.max_hap_len = hc.max_hap;
-                for (auto &rcl : rcls) {
-                    lc.min_read_len = rcl.lo; lc.max_read_len = rcl.max_len;
-                    lc.run_onhap = (++launched == total);
-                    rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
-                    if (rc) return rc;
-                }
+                lc.hap_list = class_list_dev + L.list_off;
+                lc.list_begin = (int)(std::lower_bound(hl, hl + L.list_len, g0) - hl);
+                lc.list_end = (int)(std::lower_bound(hl, hl + L.list_len, g1) - hl);
+                lc.max_hap_len = L.max_hap_len;
+                lc.min_read_len = L.min_read_len; lc.max_read_len = L.max_read_len;
+                lc.max_window_reads = L.max_window_reads; lc.avg_window_reads = L.avg_window_reads;
+                lc.run_onhap = (i == lcls.n_launches - 1);
+                rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
+                if (rc) return rc;
             }
         }
         if (!staged && c > 0 && (rc = download(c - 1))) return rc;

@@ -59,6 +59,7 @@ struct KernelArgs {
     int32_t always_ro;                   /* 1: never skip the RO sink chain speculatively (diagnostics / A-B) */
     /* launch geometry */
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
+    int32_t reads_per_wave;              /* main kernel, ragged batches: > 0 = a haplotype uses only ceil(its reads / (waves x this)) of its n_split slices */
     int32_t item_begin;                  /* this launch covers items [item_begin, n_items) (chunked host path) */
     int32_t read_begin, read_end;        /* reads covered by this launch (onHap kernel) */
     const int32_t *hap_list;             /* length-class launches: haplotype of item i is hap_list[i / n_split]; NULL = identity */
@@ -74,6 +75,7 @@ struct KernelArgs {
     /* half-wave builds: bytes of one pair's rows inside a wavefront's region (rows of pair q at q * lds_group_bytes; the back-pointer tile
      * is the wavefront's), and the block-shared sort keys */
     uint32_t lds_group_bytes, lds_off_S;
+    uint32_t bt_wave_bytes;              /* GBT builds: bytes of a wavefront's scratch region = back-pointer tile (bt_rows x 64 words) + beta[bMid] stash */
 };
 
 /* Workgroups are dealt round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own L2.  The haplotypes of a
@@ -93,7 +95,7 @@ __device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
  * DD_BUILD_TWO_WAVES: the K = 3 / D = 6 scratch build compiled for 2 waves per SIMD instead of 3 */
 #define DD_BUILD_FOLD 1
 #define DD_BUILD_TWO_WAVES 2
-#define DD_BUILD_HALF 4       /* two pairs per wavefront on 32-lane halves (K positions per lane of a half): K = 1, 2, 3, 5, 7 */
+#define DD_BUILD_HALF 4       /* two pairs per wavefront on 32-lane halves (K positions per lane of a half): K = 1, 3, 5, 7 */
 hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */

@@ -167,7 +167,7 @@ __device__ __forceinline__ void mark_unsupported(const dd_result &o, int64_t pai
 }
 
 #ifndef DD_LEAN_RULE
-#define DD_LEAN_RULE(K, D, GBT) ((GBT) && ((D) > 7 || (K) >= 3))
+#define DD_LEAN_RULE(K, D, GBT, G) (((GBT) || (G) > 1) && ((D) > 7 || (K) >= 3))
 #endif
 template <int K, int D> struct BtPack {
     static constexpr int CB = (D <= 7) ? 3 : 4;
@@ -201,7 +201,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // the CU anyway — there the 3-wave build's spills cost 9 % and buy nothing (profiles/r03/plan_check.jsonl).
 // G: pairs a wavefront works on at a time.  G = 2 (round 4): two reads of the haplotype side by side on the two 32-lane halves, K
 // positions per lane of a half, so a pair costs K / 2 lane-positions per read base instead of ceil((Hs + 2) / 64): haplotypes of
-// 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), <= 62 bp as K = 2 / 1 halves.
+// 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves, <= 30 bp as K = 1 halves (capi.cpp kHapClasses).
 // The two reads advance base by base together (their trip counts are padded to the longer one, the shorter one's lanes masked off), so
 // the workgroup first orders the window's reads by (bMid, bases right of bMid) and a wavefront takes two consecutive ranks.  Every
 // per-read quantity that the G = 1 build keeps on the scalar unit is a per-lane value here, equal across the lanes of a half.
@@ -249,16 +249,28 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // LEAN (HBM-scratch builds with D > 7 or K >= 3): the two [K][D] per-lane constant arrays (88 VGPRs at K = 2, D = 11) do not fit next
     // to the slice window at 3 waves/SIMD; the Inc constants come from a block-shared LDS table instead (LDS is idle in
     // this build) and the Dec jump penalties are formed on the fly from E[x] and a broadcast (y-1)*II.
-    constexpr bool LEAN = DD_LEAN_RULE(K, D, GBT);
+    constexpr bool LEAN = DD_LEAN_RULE(K, D, GBT, G);
+    // SLIM (K >= 3 or two pairs per wavefront): the builds that sit at their register budget keep less alive across the sweeps —
+    // the per-position constants of a pass are (re)loaded from the haplotype's LDS tables right in front of that pass instead of once
+    // per haplotype (their loads cannot be hoisted: the index goes through an opaque register), beta[bMid] waits in a wave-private LDS
+    // row while the left->middle pass runs (4 K registers; scratch builds only: behind the wave's back-pointer tile, one coalesced
+    // 8-byte store / load per position per read — an LDS row for it cost the K = 5 builds two of their eight waves per CU), and with two pairs per wavefront the per-read addresses are formed again
+    // after the sweeps instead of being carried through them.  (Round 4: the K = 5 half-wave build spilled 59 registers, 5 scratch
+    // accesses inside the right->middle sweep, without this.)
+    constexpr bool SLIM = (K >= 3) || (G > 1);
+    constexpr bool STASH = SLIM && GBT;            // beta[bMid] parked behind the wave's back-pointer tile in the HBM scratch: [2 K][64] doubles
     double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][W] lp_y(src)+Nn[src]
     double *shY = reinterpret_cast<double *>(smem + P.lds_off_Y);  // LEAN: [D] (y-1)*II
     typedef BtPack<K, D> BP;
     typedef typename BtWord<BP::BYTES>::type btword_t;
     typedef typename BtWord<(BP::BYTES == 8 ? 8 : 4)>::type btacc_t;   // register type the word is assembled in
     btword_t *bt;                                                          // [Lmax][64] packed back-pointers
-    if constexpr (GBT)
-        bt = reinterpret_cast<btword_t *>(P.bt_scratch) + (size_t)(blockIdx.x * nwav + wave) * (size_t)P.bt_rows * 64;
-    else
+    double *beS = nullptr;
+    if constexpr (GBT) {
+        unsigned char *tile = reinterpret_cast<unsigned char *>(P.bt_scratch) + (size_t)(blockIdx.x * nwav + wave) * (size_t)P.bt_wave_bytes;
+        bt = reinterpret_cast<btword_t *>(tile);
+        beS = reinterpret_cast<double *>(tile + (size_t)P.bt_rows * 64 * sizeof(btword_t));
+    } else
         bt = reinterpret_cast<btword_t *>(wave_base + P.lds_off_bt);
     // G = 2: the workgroup's order of a chunk of the window's reads (sort keys, then read index by rank)
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + P.lds_off_S);     // [DD_HALF_CHUNK]
@@ -286,6 +298,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         const int64_t pb = P.win_pair_off[w] + (int64_t)(g - h0) * R;
         for (int ri = split * nthr + tid; ri < R; ri += P.n_split * nthr) mark_unsupported(P.out, pb + ri);
         continue;
+    }
+    // workgroups this haplotype's reads are dealt to: the launch's n_split, or — ragged batches — as many as give a wavefront
+    // about P.reads_per_wave reads (the other workgroups of the haplotype have nothing to do and leave before the set-up)
+    int nsp = P.n_split;
+    if (P.reads_per_wave > 0) {
+        nsp = ((R + G - 1) / G + nwav * P.reads_per_wave - 1) / (nwav * P.reads_per_wave);
+        nsp = nsp < 1 ? 1 : (nsp > P.n_split ? P.n_split : nsp);
+        if (split >= nsp) continue;
     }
     const int hs_off = P.hap_seq_off[g];
     const int Hs = P.hap_seq_off[g + 1] - hs_off;
@@ -356,14 +376,25 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     const int laneRO = RO / K, kRO = RO - laneRO * K;
     double lpn[K], eIn[K], eInc[K], niDec[K];
     uint32_t mOwn[K];                               // bit c: this state's emission is eq for read column c
+    auto load_dec_constants = [&](int xb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int x = xb + k;
+            const bool valid = x < numS;
+            lpn[k] = valid ? shN[x] : NEG_INF;      // Dec: logProbNoError[x]
+            eIn[k] = valid ? shE[x] : NEG_INF;      // Dec: logProbError[x]   (insertion-open into x)
+            niDec[k] = (x == 0) ? NEG_INF : NI;     // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
+        }
+    };
+    auto load_inc_constants = [&](int xb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) eInc[k] = (xb + k + 1 <= RO) ? shE[xb + k + 1] : NEG_INF;   // Inc: logProbError[x+1]
+    };
+    if constexpr (!SLIM) { load_dec_constants(x0); load_inc_constants(x0); }
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int x = x0 + k;
         const bool valid = x < numS;
-        lpn[k] = valid ? shN[x] : NEG_INF;          // Dec: logProbNoError[x]
-        eIn[k] = valid ? shE[x] : NEG_INF;          // Dec: logProbError[x]   (insertion-open into x)
-        eInc[k] = (x + 1 <= RO) ? shE[x + 1] : NEG_INF;   // Inc: logProbError[x+1]
-        niDec[k] = (x == 0) ? NEG_INF : NI;         // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
         // bit c set <=> code_match(state symbol, c): 'N' / LO / RO match every column, another symbol its own, a pad none
         const unsigned scode = sc[x];
         mOwn[k] = !valid ? 0u : (scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u));
@@ -497,13 +528,14 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         }
         nch = __builtin_amdgcn_readfirstlane(lo);
     }
-    for (int rb = (split * nwav + wave) * G; rb < nch; rb += P.n_split * nwav * G) {
+    for (int rb = (split * nwav + wave) * G; rb < nch; rb += nsp * nwav * G) {
         // G = 2: the second pair of the last wavefront may be missing: its lanes run the code with an empty read and store nothing
         const bool live = (G == 1) || (rb + grp < nch);
-        const int ri = (G == 1) ? rb : chunk0 + (live ? (int)sord[rb + grp] : (int)sord[rb]);
-        const int r = r0 + ri;
-        const int64_t pair = pair_base + ri;
-        const int so = P.read_seq_off[r];
+        // (G = 2: ri, L and bMid are what a lane carries through the sweeps; r, pair and so are formed again behind them)
+        int ri = (G == 1) ? rb : chunk0 + (live ? (int)sord[rb + grp] : (int)sord[rb]);
+        int r = r0 + ri;
+        int64_t pair = pair_base + ri;
+        int so = P.read_seq_off[r];
         const int Lread = P.read_seq_off[r + 1] - so;
         const int L = live ? Lread : 0;
 
@@ -548,6 +580,11 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             const bool valid = (x0 + k) < numS;
             a[k] = valid ? 0.0 : NEG_INF;      // beta[L-1][*] = 0
             in[k] = valid ? 0.0 : NEG_INF;
+        }
+        if constexpr (SLIM) {
+            int xb = x0;
+            asm volatile("" : "+v"(xb));       // opaque: the loads below stay inside this read's code, in front of the pass that uses them
+            load_inc_constants(xb);
         }
         {
             double cInc[LEAN ? 1 : K][LEAN ? 1 : D];   // lp_y(src)+Nn[src] for src = x+y  (:1730-1735)
@@ -679,7 +716,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         STAMP(3);   // Inc passes
         double be_a[K], be_i[K];           // beta[bMid]
 #pragma unroll
-        for (int k = 0; k < K; k++) { be_a[k] = a[k]; be_i[k] = in[k]; }
+        for (int k = 0; k < K; k++) {
+            be_a[k] = a[k]; be_i[k] = in[k];
+            if constexpr (STASH) { beS[(2 * k) * 64 + wlane] = a[k]; beS[(2 * k + 1) * 64 + wlane] = in[k]; }   // parked until the join (the same lane writes and reads)
+        }
         if (foldLO) {                      // LO's beta back to position 0, where the join and the left->middle pass have it
             const double tA = __shfl(a[K - 1], 63), tI = __shfl(in[K - 1], 63);
             if (lane == 0) { be_a[0] = tA; be_i[0] = tI; }
@@ -701,6 +741,11 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             const bool valid = (x0 + k) < numS;
             a[k] = valid ? 0.0 : NEG_INF;      // alpha[0][*] = 0 (:335-338)
             in[k] = valid ? 0.0 : NEG_INF;
+        }
+        if constexpr (SLIM) {
+            int xb = x0;
+            asm volatile("" : "+v"(xb));
+            load_dec_constants(xb);
         }
         {
             double lpDec[LEAN ? 1 : K][LEAN ? 1 : D];   // y=1: Nn[x]; y>=2: E[x]+(y-1)*II   (:1786-1791)
@@ -816,6 +861,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         {
             const double eq = rdE[2 * bMid], uq = rdE[2 * bMid + 1];
             const int col = rdC[bMid];
+            if constexpr (G > 1) { asm volatile("" : "+v"(ri)); r = r0 + ri; }
             const int mqi = P.read_mqidx[r];
             const double prOff0 = T[T_MAPQ + 4 * mqi + 0], prOff1 = T[T_MAPQ + 4 * mqi + 1];
             const double prOn0 = T[T_MAPQ + 4 * mqi + 2], prOn1 = T[T_MAPQ + 4 * mqi + 3];
@@ -850,8 +896,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             for (int k = 0; k < K; k++) {
                 const int x = x0 + k;
                 const double o = ((mOwn[k] >> col) & 1u) ? eq : uq;
-                const double baseA = (a[k] + o) + be_a[k];              // alpha + obs + beta (:1098)
-                const double baseI = (in[k] + eq) + be_i[k];
+                const double bA = STASH ? beS[(2 * k) * 64 + wlane] : be_a[k], bI = STASH ? beS[(2 * k + 1) * 64 + wlane] : be_i[k];
+                const double baseA = (a[k] + o) + bA;                   // alpha + obs + beta (:1098)
+                const double baseI = (in[k] + eq) + bI;
                 double pOn0 = prOn0, pOn1 = prOn1, qOn0 = hqOn0, qOn1 = hqOn1, pOf0 = prOff0, pOf1 = prOff1, qOf0 = hqOff0, qOf1 = hqOff1;
                 if (usePin) {
                     int d = pinD0 + x;
@@ -885,6 +932,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         }
         }
         STAMP(4);   // join
+        if constexpr (G > 1) {
+            asm volatile("" : "+v"(ri));
+            r = r0 + ri; pair = pair_base + ri; so = P.read_seq_off[r];
+        }
         const int xR = mapRMQ % numS, xH = mapHMQ % numS;
         const bool offHap = (xR == 0 || xR == RO);
         const bool offHapHMQ = (xH == 0 || xH == RO);
@@ -1252,13 +1303,12 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
     }
 }
 
-// half-wave builds (two pairs per wavefront): K = 1, 2, 3, 5, 7 positions per lane of a 32-lane half
+// half-wave builds (two pairs per wavefront): K = 1, 3, 5, 7 positions per lane of a 32-lane half
 template <int D, bool GBT>
 static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
     switch (K) {
     case 1: return launch_one<1, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
-    case 2: return launch_one<2, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 3: return launch_one<3, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 5: return launch_one<5, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 7: return launch_one<7, D, GBT, false, 0, 2>(A, grid, waves, lds, st);

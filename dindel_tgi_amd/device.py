@@ -77,15 +77,17 @@ class DeviceBatch:
         if self.n_skipped:
             t["win_skip"] = _to_dev(skip, self.device)
         self.classes = capi.dd_length_classes()
-        hcl = np.zeros(max(pb.n_haps, 1), np.int32)
-        if lib.dd_build_length_classes(C.byref(hb), skip.ctypes.data_as(capi.c_u8p) if self.n_skipped else None,
+        hcl = np.zeros(max(pb.n_haps, 1) * capi.N_READ_CLASSES, np.int32)
+        if lib.dd_build_length_classes(C.byref(hb), skip.ctypes.data_as(capi.c_u8p) if self.n_skipped else None, C.byref(params),
                                        hcl.ctypes.data_as(capi.c_i32p), C.byref(self.classes)) != 0:
             raise RuntimeError("dd_build_length_classes: " + capi.last_error())
-        t["hap_class_list"] = _to_dev(hcl, self.device)
+        t["hap_class_list"] = _to_dev(hcl[:max(self.classes.list_len, 1)], self.device)
         self.t = t
         db = capi.dd_device_batch()
         db.n_windows, db.n_haps, db.n_reads = pb.n_windows, pb.n_haps, pb.n_reads
         db.max_hap_len, db.max_read_len = max(int(ok_max[0]), 1), max(int(ok_max[1]), 1)
+        nr = np.diff(a["win_read_off"])
+        db.max_window_reads = int(nr[skip[:pb.n_windows] == 0].max()) if pb.n_windows and (skip[:pb.n_windows] == 0).any() else 0
         for k, v in t.items():
             setattr(db, k, v.data_ptr())
         db.n_qual, db.n_mapq = hb.n_qual, hb.n_mapq

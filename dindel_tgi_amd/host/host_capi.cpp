@@ -762,6 +762,39 @@ int ddh_parse_inputs_json(const char *varFile, int oneBased, const char *libFile
     }
 }
 
+// The window file call by call: what every getLineVector() of the loop `while (!vf.eof())` returned (the candidates, or "skipped"), and the
+// string that ended the loop if one was thrown — the format of oracle/ref_bits.cpp:ref_window_lines_json, which runs the reference's own
+// VariantFile.hpp over the same file (tests/test_ref_bits.py).
+int ddh_window_lines_json(const char *varFile, int oneBased, char *out, int cap)
+{
+    std::ostringstream os;
+    os.precision(17);
+    os << "{\"calls\":[";
+    std::string thrown;
+    bool threw = false;
+    try {
+        VariantFile vf(varFile);
+        bool first = true;
+        while (!vf.eof()) {
+            AlignedCandidates c = vf.getLineVector(oneBased != 0);
+            os << (first ? "" : ",");
+            first = false;
+            if (c.variants.empty()) { os << "\"skipped\""; continue; }
+            os << "{\"tid\":\"" << c.tid << "\",\"leftPos\":" << c.leftPos << ",\"rightPos\":" << c.rightPos << ",\"centerPos\":" << c.centerPos << ",\"variants\":[";
+            for (size_t i = 0; i < c.variants.size(); i++) {
+                const AlignedVariant &v = c.variants[i];
+                os << (i ? "," : "") << "[" << v.getStartHap() << ",\"" << v.getString() << "\"," << v.getEndHap() << "," << int(v.getType()) << "," << v.size() << ",\"" << v.getSeq()
+                   << "\"," << v.getFreq() << "," << int(v.getAddComb()) << "]";
+            }
+            os << "]}";
+        }
+    } catch (std::string &e) { threw = true; thrown = e; }
+    os << "]";
+    if (threw) os << ",\"throw\":\"" << thrown << "\"";
+    os << "}";
+    return emit(os.str(), out, cap);
+}
+
 // DetInDel::getReads over consecutive windows (win: n x {leftPos, rightPos}); prm: {maxReads, maxReadLength, minReadOverlap,
 // mapUnmappedReads}; per window the selected reads in order, or the string thrown
 int ddh_get_reads_aux_json(const char *bamPath, const char *libFile, const char *tid, const int *win, int n, const int *prm, double mapQualThreshold,

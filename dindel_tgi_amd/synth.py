@@ -136,7 +136,7 @@ def concat(parts) -> PackedBatch:
     return PackedBatch(hap_var_flank=np.concatenate(flank), **{k: np.concatenate(v) for k, v in out.items()})
 
 
-def generate_ragged(n_windows, seed=0x5EED4, max_reads=400) -> PackedBatch:
+def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_indel=12) -> PackedBatch:
     """Windows in the shapes the reference's own pipeline produces (fixed seed; bench.py's `ragged` leg, tests):
 
     * reference haplotype = [minRef - 60, maxRef + 60] around the window's candidates (python/makeWindows.py:72-75): 121 bp for a
@@ -146,14 +146,15 @@ def generate_ragged(n_windows, seed=0x5EED4, max_reads=400) -> PackedBatch:
       deletion of 1..max_indel bases (max_indel drawn per window from 1..12), so a window's haplotypes have DIFFERENT lengths;
     * 20..max_reads reads per window (log-uniform), one read length per window out of 36 / 76 / 100 / 150 bp (every fifth
       window with trimmed reads of mixed lengths), Phred 2..41 base qualities, nine mapping qualities.
+    max_extra / max_indel narrow the haplotype lengths (diagnostics: max_extra=0, max_indel=5 keeps every haplotype on one lane tiling).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     parts = []
     for i in range(n_windows):
-        extra = 0 if rng.random() < 0.45 else int(min(40, rng.geometric(1.0 / 9.0)))
+        extra = 0 if rng.random() < 0.45 else int(min(max_extra, rng.geometric(1.0 / 9.0)))
         H = int(rng.integers(2, 13))
         R = int(np.exp(rng.uniform(np.log(20.0), np.log(float(max_reads)))))
         L = int(rng.choice([36, 76, 100, 150], p=[0.1, 0.25, 0.45, 0.2]))
-        parts.append(generate(1, H=H, R=R, L=L, hap_len=121 + extra, seed=int(rng.integers(1, 2 ** 31)), max_indel=int(rng.integers(1, 13)),
+        parts.append(generate(1, H=H, R=R, L=L, hap_len=121 + extra, seed=int(rng.integers(1, 2 ** 31)), max_indel=int(rng.integers(1, max_indel + 1)),
                               vary_read_len=(i % 5 == 4), mixed_quals=True))
     return concat(parts)

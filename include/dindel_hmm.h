@@ -250,25 +250,35 @@ int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log9
 int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off,
                    int64_t *win_hpos_off, int64_t *win_varcov_off);
 
-/* Ragged batches: haplotypes are grouped by the lane tiling they need and reads into "<= 160 bp" / "longer"; every
- * non-empty (haplotype class, read class) gets its own launch plan, so one long haplotype or read does not put the whole
- * batch on the slower build.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the
- * summary once on the host (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
+/* Ragged batches: every launch covers one (lane tiling of the haplotypes, read-length interval), so one long haplotype or read does not
+ * put the whole batch on the slower build.  The haplotype classes are the lane tilings (<= 30, 62, 94, 126, 158, 190, 222, 254, 318, ... 766 bp);
+ * the read intervals of a tiling are [1, T], (T, 160], (160, 1024] with T = the longest read whose back-pointer tile still fits LDS at full
+ * occupancy for that tiling and these params (no such cut when p is NULL).  A haplotype is listed in a launch only if its window holds a
+ * read of the interval.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the summary once on the host
+ * (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
 #define DD_N_HAP_CLASSES 16
+#define DD_N_READ_CLASSES 3
+typedef struct dd_launch_class {
+    int32_t list_off, list_len;         /* hap_class_list[list_off .. list_off + list_len): the launch's haplotypes, ascending            */
+    int32_t hap_class;                  /* lane tiling (index of the haplotype-length class)                                              */
+    int32_t max_hap_len;                /* longest haplotype of the list                                                                  */
+    int32_t min_read_len, max_read_len; /* shortest admissible read / longest read present                                                */
+    int32_t max_window_reads, avg_window_reads;   /* reads of the interval per window of the list: most, mean                             */
+} dd_launch_class;
 typedef struct dd_length_classes {
-    int32_t hap_class_off[DD_N_HAP_CLASSES + 1];  /* class c owns hap_class_list[hap_class_off[c] .. hap_class_off[c+1])   */
-    int32_t hap_class_max[DD_N_HAP_CLASSES];      /* longest haplotype of the class (0 = empty class)                      */
-    int32_t n_read_classes;                       /* 0..2                                                                  */
-    int32_t read_class_lo[2], read_class_max[2];  /* shortest admissible / longest present read length of each read class  */
+    int32_t n_launches;                 /* non-empty (tiling, interval) combinations                                                      */
+    int32_t list_len;                   /* entries of hap_class_list in use (<= n_haps * DD_N_READ_CLASSES)                               */
+    dd_launch_class launch[DD_N_HAP_CLASSES * DD_N_READ_CLASSES];
 } dd_length_classes;
-/* hap_class_list[n_haps]: haplotype indices sorted by class, ascending inside a class (host memory; copy it to the device).
- * win_skip (may be NULL = none): dd_screen_windows' flags; haplotypes of skipped windows ride in class 0 without counting
- * towards its maximum (the kernel only marks their pairs), and their reads do not count towards the read classes. */
-int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, int32_t *hap_class_list, dd_length_classes *out);
+/* hap_class_list[n_haps * DD_N_READ_CLASSES] (host memory; copy list_len entries to the device).
+ * win_skip (may be NULL = none): dd_screen_windows' flags; haplotypes of skipped windows ride in the first launch without counting
+ * towards its maxima (the kernel only marks their pairs), and their reads do not count. */
+int dd_build_length_classes(const dd_batch *b, const uint8_t *win_skip, const dd_params *p, int32_t *hap_class_list, dd_length_classes *out);
 
 typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_batch */
     int32_t n_windows, n_haps, n_reads;
     int32_t max_hap_len, max_read_len;
+    int32_t max_window_reads;       /* most reads a window has (0 = not known: every haplotype's reads are then dealt to the same number of workgroups) */
     const int32_t *win_hap_off, *win_read_off; const uint32_t *win_hap_start;
     const int32_t *hap_seq_off; const char *hap_seq; const int32_t *hap_var_off, *hap_var;
     const int32_t *read_seq_off; const char *read_seq; const uint8_t *read_qidx, *read_mqidx;

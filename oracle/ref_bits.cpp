@@ -8,11 +8,14 @@
 //   Variant.hpp              AlignedVariant       — string forms, isCovered (hapIndelCovered / hapSNPCovered, A10)
 //   ObservationModel.hpp     ObservationModelParameters::setDefaultValues — the struct defaults behind dd_params
 //   MLAlignment.hpp          the hpos codes INS / DEL / LO / RO and what the constructor zeroes (A11)
+//   VariantFile.hpp          AlignedCandidates, VariantFile::getLineVector — the realignment-window file parser (N2; round 4)
 // This file only includes them (path given by -I on the command line, see Makefile target _ref) and exports C wrappers;
 // the library goes to oracle/_ref/ and is used by tests/test_ref_bits.py to check the restatement and the host tables
 // against the reference's own code.  TEST INFRASTRUCTURE ONLY.
 #include <cmath>
 #include <cstring>
+#include <stdint.h>
+#include <sstream>
 #include <string>
 #include <vector>
 using namespace std;          // ReadIndelErrorModel.hpp relies on the including file for <vector> and the using-directive
@@ -21,6 +24,7 @@ using namespace std;          // ReadIndelErrorModel.hpp relies on the including
 #include "Variant.hpp"
 #include "MLAlignment.hpp"
 #include "ObservationModel.hpp"
+#include "VariantFile.hpp"
 
 extern "C" {
 
@@ -56,6 +60,44 @@ void ref_obs_params_defaults(double *d, int *i)
     d[0] = p.pError; d[1] = p.pMut; d[2] = p.pFirstgLO; d[3] = p.mapQualThreshold; d[4] = p.checkBaseQualThreshold; d[5] = p.capMapQualFast;
     i[0] = p.maxLengthDel; i[1] = p.maxLengthIndel; i[2] = p.padCover; i[3] = p.bMid; i[4] = p.forceReadOnHaplotype; i[5] = p.mapUnmappedReads;
     i[6] = p.maxMismatch;
+}
+
+// The window file as the reference's own parser reads it (VariantFile.hpp:188-289): one JSON entry per getLineVector() call of the
+// loop `while (!vf.eof())` (DInDel.cpp:1310-1322) — the candidates (position, string, end, type, length, sequence, prior, add-combinatorially)
+// or "skipped" for an empty result; a throw ends the list and is reported ("Cannot read left boundary of region." reaches the caller of the
+// reference's loop too, DInDel.cpp:1316).  Written in the format of dindel_tgi_amd/host/host_capi.cpp:ddh_window_lines_json, which does the
+// same with this repository's parser: tests/test_ref_bits.py compares the two texts.
+int ref_window_lines_json(const char *path, int oneBased, char *out, int cap)
+{
+    ostringstream os;
+    os.precision(17);
+    os << "{\"calls\":[";
+    string thrown;
+    bool threw = false;
+    try {
+        VariantFile vf(path);
+        bool first = true;
+        while (!vf.eof()) {
+            AlignedCandidates c = vf.getLineVector(oneBased != 0);
+            os << (first ? "" : ",");
+            first = false;
+            if (c.variants.empty()) { os << "\"skipped\""; continue; }
+            os << "{\"tid\":\"" << c.tid << "\",\"leftPos\":" << c.leftPos << ",\"rightPos\":" << c.rightPos << ",\"centerPos\":" << c.centerPos << ",\"variants\":[";
+            for (size_t i = 0; i < c.variants.size(); i++) {
+                const AlignedVariant &v = c.variants[i];
+                os << (i ? "," : "") << "[" << v.getStartHap() << ",\"" << v.getString() << "\"," << v.getEndHap() << "," << int(v.getType()) << "," << v.size() << ",\"" << v.getSeq()
+                   << "\"," << v.getFreq() << "," << int(v.getAddComb()) << "]";
+            }
+            os << "]}";
+        }
+    } catch (string &e) { threw = true; thrown = e; }
+    os << "]";
+    if (threw) os << ",\"throw\":\"" << thrown << "\"";
+    os << "}";
+    const string t = os.str();
+    if (int(t.size()) + 1 > cap) return -int(t.size()) - 1;
+    memcpy(out, t.c_str(), t.size() + 1);
+    return int(t.size());
 }
 
 // MLAlignment codes and constructor values — MLAlignment.hpp:31-46

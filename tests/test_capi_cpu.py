@@ -172,10 +172,10 @@ def test_launch_plan_rules(lib, monkeypatch):
         assert lib.dd_plan_info(C.byref(p), hap, L, 1, reads, haps, C.byref(out)) == 0, capi.last_error()
         return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7], G=out[8])
     # lane tiling by haplotype length: numS = Hs+2 <= 64 K on a whole wavefront, or <= 32 K on a half (two pairs per wavefront, round 4)
-    # where that is the tighter fit: <= 30, <= 62, 63..94, 127..158, 191..222 bp
+    # where that is the tighter fit and measured faster: <= 30, 63..94, 127..158, 191..222 bp
     hs = (30, 31, 62, 63, 94, 95, 126, 127, 158, 159, 190, 191, 222, 223, 254, 255, 318, 319, 382, 383, 446, 447, 510, 511, 702, 703, 766)
     assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in hs] == \
-        [(2, 1), (2, 2), (2, 2), (2, 3), (2, 3), (1, 2), (1, 2), (2, 5), (2, 5), (1, 3), (1, 3), (2, 7), (2, 7), (1, 4), (1, 4), (1, 5), (1, 5),
+        [(2, 1), (1, 1), (1, 1), (2, 3), (2, 3), (1, 2), (1, 2), (2, 5), (2, 5), (1, 3), (1, 3), (2, 7), (2, 7), (1, 4), (1, 4), (1, 5), (1, 5),
          (1, 6), (1, 6), (1, 7), (1, 7), (1, 8), (1, 8), (1, 9), (1, 11), (1, 12), (1, 12)]
     monkeypatch.setenv("DD_NO_HALF", "1")                      # A/B switch: whole-wavefront tilings only
     assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in (30, 62, 63, 127, 191, 222)] == [(1, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 4)]
@@ -211,17 +211,32 @@ def test_length_classes_and_library_tables_on_the_host(lib):
     pb = pack(wins, libraries=[(probs, 0.3), (np.array([1.0]), 1.0)])
     b = pb.ctypes_batch()
     cls = capi.dd_length_classes()
-    lst = np.zeros(pb.n_haps, np.int32)
-    assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    lst = np.zeros(pb.n_haps * capi.N_READ_CLASSES, np.int32)
+    p = capi.params_cli_defaults()
+    assert lib.dd_build_length_classes(C.byref(b), None, C.byref(p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
     hl = np.diff(pb.a["hap_seq_off"])
-    c = np.searchsorted(capi.HAP_CLASS_BOUNDS, hl, side="left")             # one class per lane tiling (capi.cpp kHapClasses)
-    assert list(cls.hap_class_off) == [0] + np.cumsum(np.bincount(c, minlength=16)).tolist()
-    assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    for k in range(16):
-        seg = lst[cls.hap_class_off[k]:cls.hap_class_off[k + 1]]
-        assert (c[seg] == k).all() and (np.diff(seg) > 0).all()
-        assert cls.hap_class_max[k] == (int(hl[seg].max()) if len(seg) else 0)
-    assert cls.n_read_classes == 2 and list(cls.read_class_lo) == [1, 161] and list(cls.read_class_max) == [160, 1024]
+    rl = np.diff(pb.a["read_seq_off"])
+    hc = np.searchsorted(capi.HAP_CLASS_BOUNDS, hl, side="left")             # one class per lane tiling (capi.cpp kHapClasses)
+    hw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_hap_off"]))
+    # every window here has ONE read, so each haplotype is in exactly one launch: that of (its tiling, its read's interval)
+    launches = [cls.launch[i] for i in range(cls.n_launches)]
+    assert cls.list_len == pb.n_haps == sum(L.list_len for L in launches)
+    seen = []
+    for L in launches:
+        seg = lst[L.list_off:L.list_off + L.list_len]
+        assert (np.diff(seg) > 0).all() and (hc[seg] == L.hap_class).all() and L.max_hap_len == int(hl[seg].max())
+        r = rl[hw[seg]]                                                      # the one read of each listed haplotype's window
+        assert (r >= L.min_read_len).all() and L.max_read_len == int(r.max()) and L.max_window_reads == L.avg_window_reads == 1
+        seen += seg.tolist()
+    assert sorted(seen) == list(range(pb.n_haps))
+    # read intervals: [1, T] (back-pointer tile in LDS at full occupancy: plan without HBM scratch), (T, 160], (160, 1024]
+    k2 = [L for L in launches if L.hap_class == 3]                           # 95..126 bp: the (126, 161) window and the shorter haplotype of (127, 160)
+    assert [(L.max_read_len, L.list_len) for L in k2] == [(160, 1), (161, 2)] and k2[1].min_read_len == 161 and 100 < k2[0].min_read_len <= 160
+    k1 = [L for L in launches if L.hap_class == 1]                           # 31..62 bp: (50, 36), (62, 100) and the shorter haplotype of (63, 100)
+    assert [(L.min_read_len, L.max_read_len, L.list_len) for L in k1] == [(1, 100, 5)]
+    # without params there is no cut at T: [1, 160], (160, 1024]
+    assert lib.dd_build_length_classes(C.byref(b), None, None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    assert sorted({cls.launch[i].min_read_len for i in range(cls.n_launches)}) == [1, 161]
     lp = np.zeros(5); l95 = np.zeros(2)
     assert lib.dd_build_library_tables(C.byref(b), lp.ctypes.data_as(capi.c_f64p), l95.ctypes.data_as(capi.c_f64p)) == 0
     assert lp.tolist() == [math.log(x) for x in (0.1, 0.2, 0.3, 0.4, 1.0)] and l95.tolist() == [math.log(0.3), 0.0]
@@ -247,13 +262,15 @@ def test_screen_windows_flags_only_the_offending_windows(lib):
     assert lib.dd_screen_windows(C.byref(b), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 3
     assert skip.tolist() == [0, 1, 1, 0, 1] and list(mx) == [130, 80]
     cls = capi.dd_length_classes()
-    lst = np.zeros(pb.n_haps, np.int32)
-    assert lib.dd_build_length_classes(C.byref(b), skip.ctypes.data_as(capi.c_u8p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
-    assert sorted(lst.tolist()) == list(range(pb.n_haps))
-    assert list(cls.hap_class_max) == [1, 0, 0, 100, 130] + [0] * 11     # class 0 holds the skipped haplotypes only
-    assert list(cls.hap_class_off) == [0, 4, 4, 4, 6] + [8] * 12
-    assert cls.n_read_classes == 1 and cls.read_class_max[0] == 80
-    assert lib.dd_build_length_classes(C.byref(b), None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == capi.DD_ERR_UNSUPPORTED
+    lst = np.zeros(pb.n_haps * capi.N_READ_CLASSES, np.int32)
+    p = capi.params_cli_defaults()
+    assert lib.dd_build_length_classes(C.byref(b), skip.ctypes.data_as(capi.c_u8p), C.byref(p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
+    # the haplotypes of the skipped windows (2, 3, 4, 7) ride in the first launch without counting towards its maxima
+    L0, L1 = cls.launch[0], cls.launch[1]
+    assert cls.n_launches == 2 and cls.list_len == pb.n_haps
+    assert lst[L0.list_off:L0.list_off + L0.list_len].tolist() == [0, 2, 3, 4, 5, 7] and (L0.hap_class, L0.max_hap_len, L0.max_read_len) == (3, 100, 80)
+    assert lst[L1.list_off:L1.list_off + L1.list_len].tolist() == [1, 6] and (L1.hap_class, L1.max_hap_len, L1.max_read_len) == (4, 130, 80)
+    assert lib.dd_build_length_classes(C.byref(b), None, C.byref(p), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == capi.DD_ERR_UNSUPPORTED
     pb2 = pack([limit, good])
     assert lib.dd_screen_windows(C.byref(pb2.ctypes_batch()), skip.ctypes.data_as(capi.c_u8p), C.byref(mx)) == 0
     assert list(mx) == [766, 1024]

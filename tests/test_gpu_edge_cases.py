@@ -341,10 +341,11 @@ def test_device_pointer_path_uses_length_classes(lib):
     c = dev.classes
     hl = np.diff(pb.a["hap_seq_off"])
     cls = np.searchsorted(capi.HAP_CLASS_BOUNDS, hl, side="left")
-    assert list(c.hap_class_off) == [0] + np.cumsum(np.bincount(cls, minlength=16)).tolist()
-    assert [int(x) for x in c.hap_class_max] == [int(hl[cls == k].max()) if (cls == k).any() else 0 for k in range(16)]
+    launches = [c.launch[i] for i in range(c.n_launches)]
+    assert sorted({L.hap_class for L in launches}) == sorted(set(cls.tolist()))          # every window has reads of one length: one launch per tiling ...
+    assert c.list_len == pb.n_haps and sum(L.list_len for L in launches) == pb.n_haps   # ... and interval
     rl = np.diff(pb.a["read_seq_off"])
-    assert c.n_read_classes == 2 and list(c.read_class_max) == [int(rl[rl <= 160].max()), int(rl.max())]
+    assert max(L.max_read_len for L in launches) == int(rl.max()) and min(L.min_read_len for L in launches) == 1
     dev.launch()
     torch.cuda.synchronize()
     assert_same(dev.results(), _oracle.batch(p, pb, nthreads=8), pb)
@@ -519,9 +520,9 @@ def test_k3_scratch_build_variants(lib):
     """K = 3 at D = 6: reads up to 90 bp run the LDS build, longer ones the scratch build compiled for 3 waves per SIMD, and reads so long
     that LDS keeps fewer than 12 waves on the CU (> ~250 bp) its 2-waves-per-SIMD variant — all three equal the oracle."""
     p = capi.params_cli_defaults()
-    hap = rnd(150)
+    hap = rnd(175)                                                    # 159..190 bp: three positions per lane of a whole wavefront
     alt = hap[:70] + hap[73:]
-    for L, want_name in ((76, "dd_hmm_kernel<3, 6, false, false, 0>"), (160, "dd_hmm_kernel<3, 6, true, false, 0>"), (330, "dd_hmm_kernel<3, 6, true, false, 2>")):
+    for L, want_name in ((76, "dd_hmm_kernel<3, 6, false, false, 0, 1>"), (160, "dd_hmm_kernel<3, 6, true, false, 0, 1>"), (330, "dd_hmm_kernel<3, 6, true, false, 2, 1>")):
         pb = pack([Window(1000, [hap, alt], reads_from(hap, 14, L, junk=0.1) + reads_from(alt, 6, L, junk=0.0))])
         got = run_host_api(lib, p, pb)
         assert lib.dd_kernel_name().decode() == want_name, (L, lib.dd_kernel_name().decode())
@@ -551,9 +552,10 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     want = _oracle.batch(p, pb, nthreads=8)
     assert_same(folded, want, pb)
     assert_same(plain, want, pb)
-    K = (max(len(hap), len(alt)) + 2 + 63) // 64
-    fits = 64 * K >= max(len(hap), len(alt)) + 3
-    assert name_plain.endswith("false, 0>") and name_folded.endswith("true, 0>" if fits else "false, 0>"), (name_folded, name_plain)
+    longest = max(len(hap), len(alt))
+    _, G, K = next(c for c in capi.HAP_CLASSES if longest <= c[0])
+    fits = G == 1 and 64 * K >= longest + 3                      # (the half-wave builds keep the one-lane blocks)
+    assert name_plain.endswith("false, 0, %d>" % G) and name_folded.endswith(("true, 0, %d>" if fits else "false, 0, %d>") % G), (name_folded, name_plain)
     if K == 2:
         # the two other builds that carry the fold: maxLengthDel = 10 (D build 11, LDS back-pointers) and reads long enough for the
         # scratch build at D = 6
@@ -568,4 +570,4 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
             w2 = _oracle.batch(params, batch, nthreads=8)
             assert_same(got, w2, batch)
             assert_same(ref, w2, batch)
-            assert ("<2, %s, " % tag) in name and name.endswith("true, 0>" if fits else "false, 0>"), name
+            assert ("<2, %s, " % tag) in name and name.endswith("true, 0, 1>" if fits else "false, 0, 1>"), name

@@ -102,3 +102,89 @@ def test_struct_defaults_and_hpos_codes(ref, lib):
     ref.ref_mlalignment(codes, dd, ii)
     assert list(codes) == [-1, -2, -3, -4]            # DD_HPOS_INS, DD_HPOS_DEL, DD_HPOS_LO, DD_HPOS_RO (include/dindel_hmm.h)
     assert list(dd) == [0.0, 0.0, 0.0] and list(ii) == [0, 0, 0, 0, -1]
+
+
+def _window_lines(fn, path, one_based):
+    import json
+    cap = 1 << 24
+    out = C.create_string_buffer(cap)
+    n = fn(str(path).encode(), one_based, out, cap)
+    assert n > 0, n
+    return json.loads(out.value.decode())
+
+
+def test_window_file_parser_against_the_reference_parser(ref, tmp_path, capfd):
+    """host/window_io.cpp's VariantFile::getLineVector (written from the format) against the reference's OWN parser
+    (VariantFile.hpp:188-289, compiled as it is into oracle/_ref): the same files go through both, call by call of the loop
+    `while (!vf.eof())` — tid, leftPos, rightPos, centerPos, every candidate's position / string / end / type / length / sequence /
+    prior / add-combinatorially flag, which lines are skipped, which string is thrown and where, what a trailing blank, an empty line,
+    a line without newline at the end of the file, a comment word, separators ';' and ',', repeated separators, a numeric prefix, a
+    one-based position 0 and prior / flag fields that do not parse do."""
+    from dindel_tgi_amd import hostlib
+    host = hostlib.load()
+    for fn in (ref.ref_window_lines_json, host.ddh_window_lines_json):
+        fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        fn.restype = C.c_int
+    rng = np.random.default_rng(77)
+    bases = "ACGT"
+
+    def variant():
+        kind = rng.integers(0, 11)
+        if kind < 4:
+            return "+" + "".join(rng.choice(list(bases), rng.integers(1, 6)))
+        if kind < 8:
+            return "-" + "".join(rng.choice(list(bases), rng.integers(1, 9)))
+        if kind < 10:
+            a, b = rng.choice(list(bases), 2, replace=False)
+            return "%s=>%s" % (a, b)
+        return ["*REF", "R", "+", "-", "A", "X=>Y", "+N", "-acgt", "G=>", "T=>TT"][int(rng.integers(0, 10))]      # odd ones: some parse, some throw
+
+    def candidate(pos):
+        sep = ";" if rng.random() < 0.2 else ","
+        w = "%d%s%s" % (pos, sep, variant())
+        r = rng.random()
+        if r < 0.3:
+            w += sep + ["0.25", "1e-3", ".5", "7", "-1", "x", "0.1z", ""][int(rng.integers(0, 8))]
+            if rng.random() < 0.5:
+                w += sep + ["0", "1", "2", "-3", "q", "1x", ""][int(rng.integers(0, 7))]
+        return w
+
+    def line():
+        left = int(rng.integers(0, 10 ** 6))
+        words = [str(rng.choice(["20", "chr1", "X", "GL000207.1"])), str(left), str(left + int(rng.integers(100, 200)))]
+        for _ in range(int(rng.integers(0, 5))):
+            words.append(candidate(left + int(rng.integers(30, 90))))
+        r = rng.random()
+        if r < 0.06:
+            words.insert(int(rng.integers(3, len(words) + 1)), rng.choice(["#rest", "%note", "15", "q,+A", ",+A", "15,,+A", "15,", ";;", "0,+T", "4294967296,+T", "-5,+T", "12abc,+T"]))
+        text = " ".join(words) if rng.random() < 0.9 else "\t".join(words)
+        r = rng.random()
+        if r < 0.08:
+            text += " "                                   # a blank behind the last word: not "at the end" for formatted stream input
+        elif r < 0.12:
+            text = " " + text
+        elif r < 0.16:
+            text = text.replace(" ", "  ", 1)
+        return text
+
+    files = []
+    for f in range(12):                                   # ~400 generated lines over a dozen files ...
+        lines = [line() for _ in range(int(rng.integers(20, 50)))]
+        for _ in range(int(rng.integers(0, 3))):
+            lines.insert(int(rng.integers(0, len(lines))), rng.choice(["", "20", "20 100", "20 100 200", "# comment line"]))
+        files.append("\n".join(lines) + ("\n" if f % 3 else ""))
+    files += ["20 10 20\n20 30", "20 \n", "20 x 20 15,+A\n", "20 10 y 15,+A\n20 10 20 16,+C\n", "20 10abc 20 15,+A\n", "20 10 20 15 16,+A\n",       # ... and the corners
+              "20 10 20 15,,+A\n", "20 10 20 15,+A,zz\n", "20 10 20 15,+A,0.1,q\n", "20 10 20 q,+A\n", "20 10 20 0,+A\n", "20 10 20 15;+AC;0.25 %16,+T 17,-G\n",
+              "", "\n", "\n\n20 10 20 15,+A\n", "20 10 20 15,+A", "20 10 20 15,+A \n", "20 10 20  15,+A\t16,-CC\n", "20 -10 -5 3,+A\n", "20 10 20 15,*REF 16,A=>C\n",
+              "20 1e3 20 15,+A\n", "20 10 20 15,+A,1e400\n", "20 10 20 15,+A,nan\n", "20 10 20 15,+A,0x10\n", "20 10 20 99999999999,+A\n", "20 2147483648 5 15,+A\n"]
+    n_calls = n_windows = n_throws = 0
+    for i, text in enumerate(files):
+        path = tmp_path / ("w%d.txt" % i)
+        path.write_bytes(text.encode())
+        for one_based in (0, 1):
+            want = _window_lines(ref.ref_window_lines_json, path, one_based)
+            got = _window_lines(host.ddh_window_lines_json, path, one_based)
+            assert got == want, (i, one_based, text[:200])
+            n_calls += len(want["calls"]); n_windows += sum(1 for c in want["calls"] if c != "skipped"); n_throws += "throw" in want
+    capfd.readouterr()                                     # (both parsers report skipped lines on stderr / stdout)
+    assert n_calls > 800 and n_windows > 300 and n_throws >= 6, (n_calls, n_windows, n_throws)

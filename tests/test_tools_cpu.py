@@ -7,9 +7,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _files(tmp_path, source_id, pairs=16000000, kernel="void ddk::dd_hmm_kernel<2, 6, false, true, 0>"):
+def _files(tmp_path, source_id, pairs=16000000, kernel="void ddk::dd_hmm_kernel<2, 6, false, true, 0, 1>"):
     bench = {"config": {"pairs_per_gpu": 16000000},
-             "roofline": {"kernel": "dd_hmm_kernel<2, 6, false, true, 0>", "traffic": None, "traffic_source": "stale: ..."}}
+             "roofline": {"kernel": "dd_hmm_kernel<2, 6, false, true, 0, 1>", "traffic": None, "traffic_source": "stale: ..."}}
     pmc = {"kernel": [kernel], "config": {"pairs_per_launch": pairs, "hbm_bytes_raw": 6.4e9}, "source_id": source_id}
     b, p = tmp_path / "bench.json", tmp_path / "pmc.json"
     b.write_text(json.dumps(bench))

@@ -28,7 +28,10 @@ from dindel_tgi_amd.device import DeviceBatch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 # shape: PP_SHAPE="H R L hap maxLengthDel" (default: configs[1]); the stamped build must hold the (K, D) the plan picks (DD_ONLY)
 H, R, L, hap, mld = [int(x) for x in os.environ.get("PP_SHAPE", "8 200 100 120 5").split()]
-pb = synth.generate(n, H=H, R=R, L=L, hap_len=hap, seed=3)
+if os.environ.get("PP_RAGGED"):          # real-shaped windows whose haplotypes all sit on the K = 2 tiling (116..126 bp)
+    pb = synth.generate_ragged(n, max_extra=0, max_indel=5)
+else:
+    pb = synth.generate(n, H=H, R=R, L=L, hap_len=hap, seed=3)
 params = capi.params_cli_defaults()
 params.maxLengthDel = mld
 dev = DeviceBatch(pb, params, "cuda:0")
@@ -43,4 +46,4 @@ tot = v[:8].sum()
 for i, nme in enumerate(names):
     print("%-18s %14.0f cycles  %5.1f %%   %9.0f cycles/pair" % (nme, v[i], 100 * v[i] / tot, v[i] / pb.n_pairs))
 print("total %.0f cycles/pair (wave time, incl. stamp overhead)" % (tot / pb.n_pairs))
-print("kernel", capi.last_launch(), "shape", (H, R, L, hap, mld))
+print("kernel", capi.last_launch(), "shape", (H, R, L, hap, mld), "launches", [(r["K"], r["pairs_per_wave"], r["gbt"], r["waves"], r["split"], r["n_haps"], r["min_read"], r["max_read"]) for r in capi.launch_log()])
