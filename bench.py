@@ -225,7 +225,7 @@ def ragged_leg(params, device, windows=2400, steps=3):
             cells = float((hl[hsel] * rsum[hw[hsel]]).sum())
             pos = 64 * rec["K"] // rec["pairs_per_wave"]
             launches.append({"K": rec["K"], "pairs_per_wave": rec["pairs_per_wave"], "D": rec["D"], "bt": "hbm" if rec["gbt"] else "lds", "fold": bool(rec["fold"]),
-                             "haplotypes": rec["n_haps"], "waves": rec["waves"], "read_split": rec["split"], "hap_len": [int(hl[hsel].min()), int(hl[hsel].max())] if hsel.any() else None,
+                             "haplotypes": rec["n_haps"], "waves": rec["waves"], "read_split": rec["split"], "dynamic_items": bool(rec["dynamic"]), "hap_len": [int(hl[hsel].min()), int(hl[hsel].max())] if hsel.any() else None,
                              "read_len": [rec["min_read"], rec["max_read"]], "share_of_cells": cells / pb.cells,
                              "lane_utilisation": float((hl[hsel] + 2).mean() / pos) if hsel.any() else None,
                              "ms": rec["us"] / 1e3 if rec["us"] >= 0 else None})

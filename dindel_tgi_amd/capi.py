@@ -112,7 +112,7 @@ N_HAP_CLASSES, N_READ_CLASSES = 16, 3
 
 class dd_launch_class(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("list_off", "list_len", "hap_class", "max_hap_len", "min_read_len", "max_read_len",
-                                         "max_window_reads", "avg_window_reads")]
+                                         "max_window_reads", "avg_window_reads", "avg_read_len")]
 
 
 class dd_length_classes(C.Structure):
@@ -202,7 +202,7 @@ def last_launch():
 
 
 LAUNCH_LOG_FIELDS = ["K", "pairs_per_wave", "D", "gbt", "fold", "waves", "lds_block", "grid", "split", "n_haps", "max_hap", "min_read", "max_read",
-                     "waves_per_cu", "occ", "us"]
+                     "waves_per_cu", "occ", "us", "dynamic", "reads_per_wave"]
 
 
 def launch_log():

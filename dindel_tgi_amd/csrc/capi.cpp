@@ -103,6 +103,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
         o += up16((uint32_t)K * Dt * W * 8u);
         A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
     }
+    A.lds_off_W = o;  o += 16;                   // the workgroup's work counter
     A.lds_off_S = o;
     if (G > 1) o += up16(DD_HALF_CHUNK * 6u);    // half-wave builds: sort keys (u32) + order (u16) of a chunk of the window's reads
     A.lds_shared_bytes = o;
@@ -142,6 +143,9 @@ uint32_t bt_word_bytes(int K, int Dt)
     const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
     return bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
 }
+
+// the workspace starts with the item counter of the dynamic (ragged) launches; the back-pointer tiles follow
+static const size_t DD_WS_HEADER = 256;
 
 // bytes of one wavefront's region of the HBM scratch: its back-pointer tile + (K >= 3 or half-wave builds) the [2 K][64] doubles where
 // beta[bMid] waits for the join (hmm_kernel.hip STASH)
@@ -674,11 +678,13 @@ int dd_build_tables(const dd_params *p, const double *qual_table, int n_qual, co
 }
 
 // ---- launch classes of a ragged batch ----
-// A launch = (lane tiling of the haplotypes, read-length interval).  The read intervals of a tiling are cut where its launch plan
-// changes: [1, T] while the back-pointer tile still fits LDS at full occupancy (T from make_plan: ~115 bp at K = 2), (T, 160], (160, 1024]
-// — so short reads keep the faster LDS build when a batch also holds long ones (round 3 had one "<= 160 bp" class: a batch with 150-bp
-// reads put its 100-bp reads on the scratch build, 18 % slower).  A haplotype is listed in a launch only if its window holds a read of the
-// interval: the other launches do not repeat its set-up.
+// A launch = (lane tiling of the haplotypes, read class).  Reads up to 160 bp and longer ones are separate launches, as in round 3; the
+// reads up to 160 bp of a tiling are cut once more where its launch plan changes — BY WINDOW: windows whose longest read still lets the
+// back-pointer tile sit in LDS at full occupancy (<= T, from make_plan: ~115 bp at K = 2) are one launch, the other windows (all their
+// reads up to 160 bp, short ones included) another — so windows of short reads keep the faster LDS build when a batch also holds 150-bp
+// windows (one "<= 160 bp" launch put the 100-bp reads on the scratch build, 18 % slower), and no window pays the haplotype set-up in both
+// (cutting by READ made the trimmed-read windows straddle the cut: 3.70e11 against 3.98e11 cells/s without the cut on bench.py's ragged
+// batch).  A haplotype is listed in a launch only if its window has reads for it.
 static int lds_read_threshold(const dd_params *p, int max_hap_len, int n_qual)
 {
     if (!p || check_params(p) != DD_SUCCESS) return 0;
@@ -724,7 +730,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
     }
     auto read_class = [&](int c, int len) { return len <= bound[c][0] ? 0 : (len <= bound[c][1] ? 1 : 2); };
     // pass 2: per window, which (tiling, interval) launches its haplotypes take part in
-    struct Acc { std::vector<int32_t> haps; int max_hap = 0, max_read = 0, max_reads = 0; int64_t sum_reads = 0, n_win = 0; };
+    struct Acc { std::vector<int32_t> haps; int max_hap = 0, max_read = 0, max_reads = 0; int64_t sum_reads = 0, n_win = 0, sum_len = 0; };
     std::vector<Acc> acc((size_t)DD_N_HAP_CLASSES * DD_N_READ_CLASSES);
     std::vector<int32_t> skipped;                             // haplotypes of skipped windows: marked by the first launch
     for (int w = 0; w < W; w++) {
@@ -738,11 +744,19 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
             if (seen & (1u << c)) continue;
             seen |= 1u << c;
             int cnt[DD_N_READ_CLASSES] = {0}, mx[DD_N_READ_CLASSES] = {0};
+            int64_t sl[DD_N_READ_CLASSES] = {0};
+            int mx160 = 0;                                        // the window's longest read up to 160 bp decides between classes 0 and 1
+            for (int64_t q = q0; q < q1; q++) {
+                const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
+                if (len >= 1 && len <= bound[c][1] && len > mx160) mx160 = len;
+            }
+            const int k160 = read_class(c, mx160 > 0 ? mx160 : 1);
             for (int64_t q = q0; q < q1; q++) {
                 const int len = b->read_seq_off[q + 1] - b->read_seq_off[q];
                 if (len < 1) continue;
-                const int k = read_class(c, len);
+                const int k = len <= bound[c][1] ? k160 : 2;
                 cnt[k]++;
+                sl[k] += len;
                 if (len > mx[k]) mx[k] = len;
             }
             for (int k = 0; k < DD_N_READ_CLASSES; k++) {
@@ -757,6 +771,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
                 if (mx[k] > a.max_read) a.max_read = mx[k];
                 if (cnt[k] > a.max_reads) a.max_reads = cnt[k];
                 a.sum_reads += cnt[k];
+                a.sum_len += sl[k];
                 a.n_win++;
             }
         }
@@ -775,10 +790,11 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
         off += L.list_len;
         L.hap_class = c;
         L.max_hap_len = a.max_hap > 0 ? a.max_hap : 1;
-        L.min_read_len = k == 0 ? 1 : bound[c][k - 1] + 1;
+        L.min_read_len = k == 2 ? bound[c][1] + 1 : 1;       // (class 1 = the windows with a read beyond T: all their reads up to 160 bp)
         L.max_read_len = a.max_read > 0 ? a.max_read : 1;
         L.max_window_reads = a.max_reads;
         L.avg_window_reads = a.n_win ? (int32_t)((a.sum_reads + a.n_win - 1) / a.n_win) : 0;
+        L.avg_read_len = a.sum_reads ? (int32_t)(a.sum_len / a.sum_reads) : 0;
     };
     bool first = true;
     for (int c = 0; c < DD_N_HAP_CLASSES; c++)
@@ -819,7 +835,7 @@ size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b)
                 pl.scratch_bytes > bytes)
                 bytes = pl.scratch_bytes;
         }
-    return bytes;
+    return bytes + DD_WS_HEADER;                  // the work counter of the ragged launches in front of the back-pointer tiles
 }
 
 // Enqueue the path for haplotypes [hap_begin, hap_end) and reads [read_begin, read_end) of the batch (a
@@ -831,6 +847,7 @@ struct LenClass {
     int list_begin = 0, list_end = 0;    // range of hap_list this launch covers
     int max_hap_len = 0, max_read_len = 0, min_read_len = 1;
     int max_window_reads = 0, avg_window_reads = 0;   // reads of the class per window of the list (0 = not known)
+    int avg_read_len = 0;                             // mean length of the class' reads (0 = not known)
     bool run_onhap = true;
 };
 
@@ -1041,9 +1058,9 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
         }
     }
     if (pl.gbt) {
-        if (!workspace || workspace_bytes < pl.scratch_bytes)
+        if (!workspace || workspace_bytes < pl.scratch_bytes + DD_WS_HEADER)
             return fail(DD_ERR_INVALID, "workspace too small for this shape: allocate dd_workspace_bytes() bytes");
-        A.bt_scratch = workspace;
+        A.bt_scratch = static_cast<unsigned char *>(workspace) + DD_WS_HEADER;
         A.bt_rows = cls_read;
         A.bt_wave_bytes = (uint32_t)scratch_wave_bytes(K, Dt, pl.G, cls_read);
     }
@@ -1085,15 +1102,28 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
         if (r->onHap && r->offHapHMQ && lc && lc->run_onhap) HIP_TRY(ddk::launch_onhap(A, static_cast<hipStream_t>(stream)));
         return DD_SUCCESS;
     }
+    const int64_t n_launch_items = grid;
     if (pl.grid_cap) {
         // the scratch holds grid_cap x pl.waves back-pointer tiles; smaller workgroups (thin windows) may be more numerous
         const int64_t cap = (int64_t)pl.grid_cap * pl.waves / waves;
         if (grid > cap) grid = cap;
     }
+    // Ragged launch (reads per window or read lengths spread widely): a persistent grid that draws its items from a counter
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    A.work_counter = nullptr;
+    {
+        const bool spread = A.reads_per_wave > 0 || (lc && lc->avg_read_len > 0 && lc->max_read_len * 4 > lc->avg_read_len * 5);
+        const char *e = getenv("DD_DYNAMIC");                                 // A/B: 0 = never, 1 = always
+        const bool dynamic = e ? (e[0] == '1') : spread;
+        if (dynamic && workspace && workspace_bytes >= DD_WS_HEADER && resident > 0 && n_launch_items > resident) {
+            A.work_counter = static_cast<int32_t *>(workspace);
+            HIP_TRY(hipMemsetAsync(workspace, 0, 4, st));
+            if (grid > resident) grid = resident;
+        }
+    }
     g_last_launch[0] = K; g_last_launch[1] = Dt + (pl.gbt ? 100 : 0); g_last_launch[2] = waves; g_last_launch[3] = (int32_t)lds;
     g_last_launch[4] = (int32_t)grid; g_last_launch[5] = (int32_t)split; g_last_launch[6] = (int32_t)A.lds_wave_bytes;
     g_last_launch[7] = (int32_t)A.lds_shared_bytes;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     // the build with the end states folded into the generic candidate code (hmm_kernel.hip, FOLD): K <= 2 at D build 6 with LDS
     // back-pointers, K = 2 at D build 6 with scratch back-pointers, K = 2 at D build 11 with LDS back-pointers — and every haplotype
     // of this launch leaves position 64 K - 1 idle (numS <= 64 K - 1)
@@ -1106,7 +1136,8 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
     LaunchRec rec;
     {
         const int32_t v[DD_LAUNCH_LOG_FIELDS] = {K, pl.G, Dt, pl.gbt ? 1 : 0, fold ? 1 : 0, waves, (int32_t)lds, (int32_t)grid, (int32_t)split,
-                                                 hap_end - hap_begin, cls_hap, lc ? lc->min_read_len : 1, cls_read, pl.waves_per_cu, g_last_occ, -1};
+                                                 hap_end - hap_begin, cls_hap, lc ? lc->min_read_len : 1, cls_read, pl.waves_per_cu, g_last_occ, -1,
+                                                 A.work_counter ? 1 : 0, A.reads_per_wave};
         memcpy(rec.v, v, sizeof(v));
     }
     static const bool timing = getenv("DD_LAUNCH_TIMING") != nullptr;
@@ -1158,6 +1189,7 @@ int dd_launch_device(const dd_params *p, const dd_device_batch *b, const dd_resu
             lc.max_read_len = L.max_read_len;
             lc.max_window_reads = L.max_window_reads;
             lc.avg_window_reads = L.avg_window_reads;
+            lc.avg_read_len = L.avg_read_len;
             lc.run_onhap = (i == C->n_launches - 1);
             const int rc = launch_range(MODEL_FBMAXERR, p, b, r, workspace, workspace_bytes, stream, 0, b->n_haps, 0, b->n_reads, &lc);
             if (rc) return rc;
@@ -1621,7 +1653,7 @@ static int compute_likelihoods_impl(Model model, const dd_params *p, const dd_ba
                 lc.list_end = (int)(std::lower_bound(hl, hl + L.list_len, g1) - hl);
                 lc.max_hap_len = L.max_hap_len;
                 lc.min_read_len = L.min_read_len; lc.max_read_len = L.max_read_len;
-                lc.max_window_reads = L.max_window_reads; lc.avg_window_reads = L.avg_window_reads;
+                lc.max_window_reads = L.max_window_reads; lc.avg_window_reads = L.avg_window_reads; lc.avg_read_len = L.avg_read_len;
                 lc.run_onhap = (i == lcls.n_launches - 1);
                 rc = launch_range(model, p, &db, &dr, ws[c & 1], ws_bytes, streams.s[c & 1], g0, g1, q0, q1, &lc);
                 if (rc) return rc;

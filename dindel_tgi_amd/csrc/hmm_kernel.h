@@ -61,6 +61,7 @@ struct KernelArgs {
     int32_t n_split, n_items;            /* items = haplotypes x read slices; workgroups stride over them */
     int32_t reads_per_wave;              /* main kernel, ragged batches: > 0 = a haplotype uses only ceil(its reads / (waves x this)) of its n_split slices */
     int32_t item_begin;                  /* this launch covers items [item_begin, n_items) (chunked host path) */
+    int32_t *work_counter;               /* main kernel: NULL = items by fixed stride; else a zeroed counter in device memory the workgroups draw items from */
     int32_t read_begin, read_end;        /* reads covered by this launch (onHap kernel) */
     const int32_t *hap_list;             /* length-class launches: haplotype of item i is hap_list[i / n_split]; NULL = identity */
     int32_t len_min, len_max;            /* length-class launches: only reads with len_min <= L <= len_max */
@@ -75,6 +76,7 @@ struct KernelArgs {
     /* half-wave builds: bytes of one pair's rows inside a wavefront's region (rows of pair q at q * lds_group_bytes; the back-pointer tile
      * is the wavefront's), and the block-shared sort keys */
     uint32_t lds_group_bytes, lds_off_S;
+    uint32_t lds_off_W;                  /* the workgroup's work counter (one int) */
     uint32_t bt_wave_bytes;              /* GBT builds: bytes of a wavefront's scratch region = back-pointer tile (bt_rows x 64 words) + beta[bMid] stash */
 };
 

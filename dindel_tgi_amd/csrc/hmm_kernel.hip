@@ -273,6 +273,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     } else
         bt = reinterpret_cast<btword_t *>(wave_base + P.lds_off_bt);
     // G = 2: the workgroup's order of a chunk of the window's reads (sort keys, then read index by rank)
+    // the workgroup's work counter: its wavefronts take the haplotype's reads (G = 2: pairs of ranks) one after the other as they become
+    // free, so that reads of different lengths, reads of another length class and a read count that is no multiple of the wave count
+    // do not leave a wavefront waiting at the next haplotype's barrier while another still has reads queued (round 4)
+    int *wq = reinterpret_cast<int *>(smem + P.lds_off_W);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + P.lds_off_S);     // [DD_HALF_CHUNK]
     uint16_t *sord = reinterpret_cast<uint16_t *>(skey + DD_HALF_CHUNK);   // [DD_HALF_CHUNK]
 
@@ -283,8 +287,19 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     STAMP_INIT;
 
     // ======================= loop over this workgroup's (haplotype, read-slice) items =======================
-    for (int item = P.item_begin + xcd_contiguous_block_id(P.n_items - P.item_begin); item < P.n_items; item += gridDim.x) {
+    // Static (uniform batches): workgroup b takes items b, b + gridDim, ... of an XCD-contiguous numbering.  Dynamic (ragged launches,
+    // P.work_counter != NULL): a persistent grid whose workgroups take the next item from a counter in device memory when they are
+    // done with the last one — items of a ragged launch differ 20-fold in work (reads per window x read length), and neither the
+    // in-order dispatch of a one-shot grid round-robin over the XCDs nor a fixed stride keeps 256 CUs busy to the end then.
+    for (int item = P.item_begin + xcd_contiguous_block_id(P.n_items - P.item_begin);; item += gridDim.x) {
     __syncthreads();                               // every wave is done with the previous haplotype's LDS tables
+    if (tid == 0) *wq = 0;                         // (the set-up's barriers lie between this and the first pull)
+    if (P.work_counter) {
+        if (tid == 0) wq[1] = P.item_begin + atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        item = wq[1];
+    }
+    if (item >= P.n_items) break;
     const int gi = item / P.n_split;
     const int split = item - gi * P.n_split;
     const int g = P.hap_list ? P.hap_list[gi] : gi;   // global haplotype index
@@ -490,16 +505,17 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         }
     };
     // ======================= loop over this wave's reads =======================
-    // G = 1: the wavefront takes reads split*nwav + wave, + n_split*nwav, ...  G = 2: the window's reads are taken in chunks of
-    // DD_HALF_CHUNK; every workgroup of the haplotype orders the chunk's reads of this launch's length class by (bMid, L) — the two
-    // pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) + max(bMid1, bMid2) sweeps, so they should agree in both — and its wavefronts
-    // take pairs of consecutive ranks the same round-robin way.  Results do not depend on the order.
+    // The haplotype's workgroups share its reads in contiguous blocks; inside a workgroup the wavefronts pull the next read from a counter
+    // in LDS when they are free.  G = 2: the window's reads are taken in chunks of DD_HALF_CHUNK; every workgroup of the haplotype orders
+    // the chunk's reads of this launch's length class by (bMid, L) — the two pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) +
+    // max(bMid1, bMid2) sweeps, so they should agree in both — and a pull takes two consecutive ranks.  Results do not depend on the order.
     const int nChunks = (G == 1) ? 1 : (R + DD_HALF_CHUNK - 1) / DD_HALF_CHUNK;
     for (int chunk0 = 0, ci = 0; ci < nChunks; ci++, chunk0 += DD_HALF_CHUNK) {
     int nch = R;                                   // reads this pass hands out (G = 2: the chunk's reads of this length class)
     if constexpr (G > 1) {
         const int nraw = (R - chunk0 < DD_HALF_CHUNK) ? R - chunk0 : DD_HALF_CHUNK;
         __syncthreads();                           // the previous chunk's order is no longer read
+        if (tid == 0) *wq = 0;                     // every wave has left the previous chunk's queue; two barriers before the first pull
         for (int t = tid; t < nraw; t += nthr) {
             const int rr = r0 + chunk0 + t;
             const int L = P.read_seq_off[rr + 1] - P.read_seq_off[rr];
@@ -528,7 +544,15 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         }
         nch = __builtin_amdgcn_readfirstlane(lo);
     }
-    for (int rb = (split * nwav + wave) * G; rb < nch; rb += nsp * nwav * G) {
+    // this workgroup's share: a contiguous block of the reads (G = 2: of the pairs of consecutive ranks)
+    const int nUnits = (nch + G - 1) / G, perSplit = (nUnits + nsp - 1) / nsp;
+    const int unitLo = split * perSplit, unitHi = (unitLo + perSplit < nUnits) ? unitLo + perSplit : nUnits;
+    for (;;) {
+        int unit = 0;
+        if (wlane == 0) unit = atomicAdd(wq, 1);
+        unit = unitLo + __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= unitHi) break;
+        const int rb = unit * G;
         // G = 2: the second pair of the last wavefront may be missing: its lanes run the code with an empty read and store nothing
         const bool live = (G == 1) || (rb + grp < nch);
         // (G = 2: ri, L and bMid are what a lane carries through the sweeps; r, pair and so are formed again behind them)

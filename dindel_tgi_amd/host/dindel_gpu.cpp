@@ -16,9 +16,12 @@
 // window's new records are appended pool after pool behind the survivors of the windows before — and std::sort's order inside a tie of
 // mapping qualities follows it, so a worker does not start a batch with an empty buffer: it first replays read selection over the
 // batch's look-back (the preceding windows of the chromosome back to one whose reads have all left the buffer by the batch's first
-// window), which leaves the buffer in the state the window-by-window loop would have.  What a worker cannot see is a window of an
-// earlier batch skipped AFTER read selection (an exception of the likelihood or genotyping step): the reference empties the buffer
-// after it, here the buffer carries on — same reads, possibly another order inside ties for the next ~(2 maxInsert + 200) bases.
+// window), which leaves the buffer in the state the window-by-window loop would have.  What a worker cannot see is a window skipped
+// AFTER read selection (an exception of the likelihood or genotyping step: "hapSize error.", "Nan detected", ...): the reference empties
+// the buffer after it (DInDel.cpp:1404-1405).  The writer sees it: from the window behind such a LATE skip it re-prepares, from an empty
+// buffer and window by window, every window whose buffer could still hold a record of that moment (same chromosome, leftPos less than
+// 2 maxInsert + 200 behind the first re-prepared window's rightPos) with a read fetcher, an engine and the reduce step of its own, and
+// writes those results instead of the ones prepared ahead — beyond that reach both histories hold the same records in the same order.
 // One BAM file: with a single pool the read buffer's reset (after a skipped window in the reference, DInDel.cpp:1401-1408; at
 // the head of every batch here) does not change which reads a window sees — the buffer always holds the file's reads starting in
 // [leftPos - maxInsert - 200, rightPos + maxInsert), in file order — so preparing windows ahead of their predecessors'
@@ -45,6 +48,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <thread>
 #include "compute_likelihoods.hpp"
@@ -64,6 +68,7 @@ struct WindowTask {
     const std::vector<Haplotype> *haps;
     std::string message;                 // "ok" or the skipped message
     bool skipped;
+    bool lateSkip;                       // skipped by the likelihood or genotyping step, i.e. after read selection (DInDel.cpp:1369-1408)
     std::string lines;                   // what the reduce stage wrote for this window
 };
 struct Batch {
@@ -75,7 +80,7 @@ struct Batch {
     std::vector<size_t> jobOf;
     std::vector<int> toRelease;          // windows of the batch's previous use whose parsed haplotypes are no longer needed
     // several BAM pools: the windows in front of the batch (same chromosome, file order) whose read selection is replayed first
-    struct Before { std::string tid; uint32_t leftPos, rightPos; };
+    struct Before { std::string tid; uint32_t leftPos, rightPos; int index; };
     std::vector<Before> lookBack;
 };
 typedef std::unique_ptr<Batch> BatchPtr;
@@ -194,7 +199,7 @@ int main(int argc, char **argv)
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
         a = a.substr(2);
         if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" || a == "outputRealignedBAM" ||
-            a == "prepareOnly" || a == "noLookBack") opt[a] = "1";
+            a == "prepareOnly" || a == "noLookBack" || a == "lateSkipsKnown") opt[a] = "1";
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::cerr << "Option --" << a << " needs a value\n"; return 2; }
     }
@@ -270,6 +275,20 @@ int main(int argc, char **argv)
         const BamFile headerBam(bamPaths[0]);    // "Cannot open BAM file." / "Cannot open BAM index." before anything else happens; the header for --outputRealignedBAM
         for (size_t i = 1; i < bamPaths.size(); i++) { const BamFile probe(bamPaths[i]); (void)probe; }
         HaplotypeFixture fixture(opt["hapFile"]);
+        // tests: --injectLateSkip I,J,... makes the reduce step of these windows throw "hapSize error." (a late skip, also under
+        // --prepareOnly); with --lateSkipsKnown the prepare stage is told in advance and resets its buffers behind them — the
+        // window-by-window history by construction, against which the writer's re-preparation is checked
+        std::set<int> injectedLateSkips;
+        if (has("injectLateSkip")) {
+            const std::string list = opt["injectLateSkip"];
+            for (size_t i = 0; i <= list.size();) {
+                size_t e = list.find(',', i);
+                if (e == std::string::npos) e = list.size();
+                if (e > i) injectedLateSkips.insert(atoi(list.substr(i, e - i).c_str()));
+                i = e + 1;
+            }
+        }
+        const bool lateSkipsKnown = has("lateSkipsKnown");
 
         const std::string outputPrefix = opt["outputFile"];
         const char *dumpReads = getenv("DINDEL_DUMP_READS");                       // diagnostics: what each window hands to the likelihood step
@@ -305,6 +324,36 @@ int main(int argc, char **argv)
             toPrepare.abort(); toCompute.abort(); toReduce.abort();
         };
 
+        const bool pooled = bamPaths.size() > 1 && !has("noLookBack");        // --noLookBack: diagnostics (every batch starts with an empty buffer)
+        const uint32_t bufferSpan = 2u * uint32_t(libraries.getMaxInsertSize()) + 200u;    // a record fetched for a window has left the buffer this far on
+        // ---- one window's read selection and haplotypes (the prepare workers; the writer's re-preparation behind a late skip) ----
+        auto prepareWindow = [&](ReadFetcher &fetcher, WindowTask &T) {
+            try {
+                fetcher.getReads(T.tid, T.fileLeftPos, T.fileRightPos, T.reads);
+                const WindowHaplotypes *wh = fixture.find(T.index);
+                if (!wh) throw std::string("no haplotypes for this window in the haplotype file");
+                T.haps = &wh->haps; T.leftPos = wh->leftPos; T.rightPos = wh->rightPos;
+                if (double(T.reads.size() * T.haps->size()) > maxHapReadProd) {     // :395-399
+                    std::stringstream os;
+                    os << "skipped_numhap_times_numread>" << long(maxHapReadProd);
+                    throw os.str();
+                }
+            } catch (std::string &s) {
+                T.message = skippedMessage(s);
+                T.skipped = true;
+            }
+            if (dumpReads) {
+                std::ofstream df((std::string(dumpReads) + "." + std::to_string(T.index)).c_str());
+                df.precision(17);
+                for (size_t r = 0; r < T.reads.size(); r++) {
+                    const Read &R = T.reads[r];
+                    df << R.qname << " " << R.poolID << " " << int32_t(R.pos) << " " << R.mapQual << " " << R.matePos << " " << R.mateLen << " " << R.isUnmapped() << " " << R.isPaired()
+                       << " " << R.mateIsUnmapped() << " " << R.mateIsReverse() << " " << R.mateSameTid << " " << R.posStat.first << " "
+                       << (R.library ? R.library->getMaxInsertSize() : -1) << " " << R.seq.seq << "\n";
+                }
+            }
+        };
+
         // ---- prepare: whole batches side by side, handed on in file order ----
         std::vector<double> t_prepare_of(size_t(prepareThreads), 0.0);
         std::vector<std::thread> prepareWorkers;
@@ -328,7 +377,7 @@ int main(int argc, char **argv)
                             const Batch::Before &W = b->lookBack[k];
                             bool skipped = false;
                             try { fetcher.getReads(W.tid, W.leftPos, W.rightPos, replayed); } catch (std::string &) { skipped = true; }
-                            fetcher.windowDone(skipped, W.leftPos);
+                            fetcher.windowDone(skipped || (lateSkipsKnown && injectedLateSkips.count(W.index)), W.leftPos);
                         }
                         oldTid = b->lookBack.back().tid;
                         primed = true;
@@ -336,31 +385,8 @@ int main(int argc, char **argv)
                     for (size_t i = 0; i < b->tasks.size(); i++) {
                         WindowTask &T = b->tasks[i];
                         if ((i == 0 && !primed) || T.tid != oldTid) { fetcher.newChromosome(); oldTid = T.tid; }     // DInDel.cpp:1327-1333
-                        try {
-                            fetcher.getReads(T.tid, T.fileLeftPos, T.fileRightPos, T.reads);
-                            const WindowHaplotypes *wh = fixture.find(T.index);
-                            if (!wh) throw std::string("no haplotypes for this window in the haplotype file");
-                            T.haps = &wh->haps; T.leftPos = wh->leftPos; T.rightPos = wh->rightPos;
-                            if (double(T.reads.size() * T.haps->size()) > maxHapReadProd) {     // :395-399
-                                std::stringstream os;
-                                os << "skipped_numhap_times_numread>" << long(maxHapReadProd);
-                                throw os.str();
-                            }
-                        } catch (std::string &s) {
-                            T.message = skippedMessage(s);
-                            T.skipped = true;
-                        }
-                        if (dumpReads) {
-                            std::ofstream df((std::string(dumpReads) + "." + std::to_string(T.index)).c_str());
-                            df.precision(17);
-                            for (size_t r = 0; r < T.reads.size(); r++) {
-                                const Read &R = T.reads[r];
-                                df << R.qname << " " << R.poolID << " " << int32_t(R.pos) << " " << R.mapQual << " " << R.matePos << " " << R.mateLen << " " << R.isUnmapped() << " " << R.isPaired()
-                                   << " " << R.mateIsUnmapped() << " " << R.mateIsReverse() << " " << R.mateSameTid << " " << R.posStat.first << " "
-                                   << (R.library ? R.library->getMaxInsertSize() : -1) << " " << R.seq.seq << "\n";
-                            }
-                        }
-                        fetcher.windowDone(T.skipped, T.fileLeftPos);                         // :1401-1408
+                        prepareWindow(fetcher, T);
+                        fetcher.windowDone(T.skipped || (lateSkipsKnown && injectedLateSkips.count(T.index)), T.fileLeftPos);   // :1401-1408
                     }
                     t_prepare_of[size_t(pt)] += seconds_since(t0);
                     if (!toCompute.push(b)) break;
@@ -442,9 +468,77 @@ int main(int argc, char **argv)
             catch (std::exception &e) { fail(e.what()); }
         }));
 
+        // ---- one window's lines: diploidGLF (+ the realigned BAM), or the skipped-window line (the reduce helpers; the writer's
+        //      re-preparation behind a late skip) ----
+        auto reduceWindow = [&](WindowTask &T, const WindowJob *J) {
+            std::ostringstream os;
+            OutputData local = glfData;
+            local.out = &os;
+            if (!T.skipped) {
+                try {
+                    if (injectedLateSkips.count(T.index)) throw std::string("hapSize error.");       // tests (--injectLateSkip)
+                    if (J) {
+                        if (!J->error.empty()) throw std::string(J->error);
+                        // like the reference, diploidGLF writes its lines as it goes: if it throws half-way ("genotyping
+                        // error"), the lines already written stay and the skipped-window line follows them
+                        diploidGLF(*T.haps, T.reads, J->result, T.pos, T.leftPos, T.rightPos, local, T.index, T.tid, T.candidates, dip, "dip");
+                        if (realignedBAM) {                                      // DInDel.cpp:589-620
+                            const std::pair<int, int> best = maxLikelihoodPair(*T.haps, T.reads, J->result, int(T.leftPos), T.candidates, dip);
+                            std::vector<CIGAR> cigars;
+                            realignedCigars(*T.haps, T.reads, J->result, best, int(T.leftPos), cigars);
+                            std::vector<int> onHap(T.reads.size());
+                            for (size_t r = 0; r < onHap.size(); r++) onHap[r] = J->result.onHap(r);
+                            writeRealignedBAMFile(realignedBAMFileName(outputPrefix, T.index, T.tid, T.leftPos, T.rightPos, rsp.minReadOverlap),
+                                                  cigars, T.reads, onHap, headerBam);
+                        }
+                    }
+                } catch (std::string &s) {
+                    T.message = skippedMessage(s);
+                    T.skipped = true;
+                    T.lateSkip = true;                                           // after read selection: the reference resets its read buffer behind it (:1404-1405)
+                }
+            }
+            if (T.skipped) local.output(skippedWindowLine(local, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
+            T.lines = os.str();
+        };
+
         // ---- reduce: windows of a batch side by side, each into its own buffer; written out in window order ----
+        long nRePrepared = 0;
         std::thread reduceThread([&]() {
             BatchPtr b;
+            // Several pools: the windows behind a late skip, re-prepared window by window from an empty buffer (see the header).  The
+            // fetcher, its BAM handles and the engine are made when the first late skip of the run is met.
+            struct Redo {
+                bool active, first;
+                std::string tid; uint64_t reach;
+                std::vector<std::unique_ptr<BamFile> > handles; std::vector<BamFile *> bams;
+                std::unique_ptr<ReadFetcher> fetcher; std::unique_ptr<LikelihoodEngine> engine;
+                Redo() : active(false), first(false), reach(0) {}
+            } redo;
+            auto rePrepare = [&](WindowTask &T) {
+                if (!redo.fetcher) {
+                    for (size_t i = 0; i < bamPaths.size(); i++) { redo.handles.push_back(std::unique_ptr<BamFile>(new BamFile(bamPaths[i]))); redo.bams.push_back(redo.handles.back().get()); }
+                    redo.fetcher.reset(new ReadFetcher(redo.bams, libraries, rsp));
+                }
+                if (redo.first) { redo.fetcher->newChromosome(); redo.reach = uint64_t(T.fileRightPos) + bufferSpan; redo.first = false; }   // the reset of DInDel.cpp:1404-1405
+                T.skipped = false; T.lateSkip = false; T.message = "ok";
+                prepareWindow(*redo.fetcher, T);
+                std::vector<WindowJob> one;
+                if (!T.skipped && !prepareOnly) {
+                    if (!redo.engine) {
+                        redo.engine.reset(new LikelihoodEngine(obs, devices[0]));
+                        redo.engine->setThrowOnPositiveLikelihood(false);
+                        redo.engine->setKeepAlignments(faster || realignedBAM);
+                    }
+                    WindowJob J;
+                    J.haps = T.haps; J.reads = &T.reads; J.leftPos = T.leftPos; J.rightPos = T.rightPos;
+                    one.push_back(J);
+                    if (faster) redo.engine->computeLikelihoodsFasterBatch(one); else redo.engine->computeLikelihoodsBatch(one);
+                }
+                reduceWindow(T, one.empty() ? NULL : &one[0]);
+                redo.fetcher->windowDone(T.skipped, T.fileLeftPos);
+                nRePrepared++;
+            };
             try {
                 while (toReduce.pop(b)) {
                     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -458,33 +552,7 @@ int main(int argc, char **argv)
                         for (;;) {
                             const size_t i = next.fetch_add(1);
                             if (i >= B.tasks.size()) break;
-                            WindowTask &T = B.tasks[i];
-                            std::ostringstream os;
-                            OutputData local = glfData;
-                            local.out = &os;
-                            if (!T.skipped && !prepareOnly) {
-                                const WindowJob &J = B.jobs[B.jobOf[i]];
-                                try {
-                                    if (!J.error.empty()) throw std::string(J.error);
-                                    // like the reference, diploidGLF writes its lines as it goes: if it throws half-way ("genotyping
-                                    // error"), the lines already written stay and the skipped-window line follows them
-                                    diploidGLF(*T.haps, T.reads, J.result, T.pos, T.leftPos, T.rightPos, local, T.index, T.tid, T.candidates, dip, "dip");
-                                    if (realignedBAM) {                                      // DInDel.cpp:589-620
-                                        const std::pair<int, int> best = maxLikelihoodPair(*T.haps, T.reads, J.result, int(T.leftPos), T.candidates, dip);
-                                        std::vector<CIGAR> cigars;
-                                        realignedCigars(*T.haps, T.reads, J.result, best, int(T.leftPos), cigars);
-                                        std::vector<int> onHap(T.reads.size());
-                                        for (size_t r = 0; r < onHap.size(); r++) onHap[r] = J.result.onHap(r);
-                                        writeRealignedBAMFile(realignedBAMFileName(outputPrefix, T.index, T.tid, T.leftPos, T.rightPos, rsp.minReadOverlap),
-                                                              cigars, T.reads, onHap, headerBam);
-                                    }
-                                } catch (std::string &s) {
-                                    T.message = skippedMessage(s);
-                                    T.skipped = true;
-                                }
-                            }
-                            if (T.skipped) local.output(skippedWindowLine(local, T.message, T.index, T.tid, T.fileLeftPos, T.fileRightPos));
-                            T.lines = os.str();
+                            reduceWindow(B.tasks[i], (!B.tasks[i].skipped && !prepareOnly) ? &B.jobs[B.jobOf[i]] : NULL);
                         }
                         } catch (std::exception &e) { next.store(B.tasks.size()); fail(std::string("reduce: ") + e.what()); }
                         catch (...) { next.store(B.tasks.size()); fail("reduce: unknown exception"); }
@@ -498,7 +566,13 @@ int main(int argc, char **argv)
                     work();
                     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
                     for (size_t i = 0; i < B.tasks.size(); i++) {
-                        const WindowTask &T = B.tasks[i];
+                        WindowTask &T = B.tasks[i];
+                        if (redo.active) {
+                            // (a new chromosome resets the buffer in both histories; beyond `reach` no record of the reset's moment is left)
+                            if ((redo.first && T.tid != redo.tid) || (!redo.first && (T.tid != redo.tid || uint64_t(T.fileLeftPos) >= redo.reach))) redo.active = false;
+                            else rePrepare(T);
+                        }
+                        if (T.lateSkip && pooled && !lateSkipsKnown) { redo.active = true; redo.first = true; redo.tid = T.tid; }
                         if (T.skipped) {
                             std::cerr << "skipped " << T.tid << " " << T.pos << " reason: " << T.message << std::endl;     // DInDel.cpp:1383
                             nSkipped++;
@@ -517,6 +591,8 @@ int main(int argc, char **argv)
                     t_reduce += seconds_since(t0);
                 }
             } catch (std::string &s) { fail(s); }
+            catch (ReadFetcher::FatalError &e) { fatalExit = e.exitCode; fail(e.message); }   // (the re-preparation behind a late skip reads the BAM files too)
+            catch (HaplotypeFixture::Error &e) { fail(e.message); }
             catch (std::exception &e) { fail(e.what()); }
         });
 
@@ -530,8 +606,6 @@ int main(int argc, char **argv)
             uint32_t oldLeftPos = 0;
             BatchPtr batch = recycled.take();
             size_t nTasks = 0;                                                                // batch->tasks[nTasks...] are left-overs of an earlier use
-            const bool pooled = bamPaths.size() > 1 && !has("noLookBack");        // --noLookBack: diagnostics (every batch starts with an empty buffer)
-            const uint32_t bufferSpan = 2u * uint32_t(libraries.getMaxInsertSize()) + 200u;    // a record fetched for a window has left the buffer this far on
             std::deque<Batch::Before> recent;                                                 // the chromosome's windows so far that a later batch may need
             auto flush = [&]() {
                 batch->seq = seq++;
@@ -571,10 +645,10 @@ int main(int argc, char **argv)
                 T.lines.clear();
                 T.candidates = cand; T.tid = cand.tid; T.pos = uint32_t(cand.centerPos);
                 T.fileLeftPos = T.leftPos = uint32_t(cand.leftPos); T.fileRightPos = T.rightPos = uint32_t(cand.rightPos);
-                T.haps = NULL; T.skipped = false; T.message = "ok";
+                T.haps = NULL; T.skipped = false; T.lateSkip = false; T.message = "ok";
                 T.index = ++index;
                 if (pooled) {
-                    Batch::Before W = { T.tid, T.fileLeftPos, T.fileRightPos };
+                    Batch::Before W = { T.tid, T.fileLeftPos, T.fileRightPos, T.index };
                     recent.push_back(W);
                 }
                 // the first batches are small (an eighth, a quarter, half of --batchWindows): the GPU gets its first windows while the bulk is
@@ -598,6 +672,7 @@ int main(int argc, char **argv)
         if (!fatal.empty()) { std::cerr << "Exception: " << fatal << std::endl; return fatalExit.load(); }
         if (rc) return rc;
         if (!has("quiet")) std::cout << "windows: " << nWindows << " skipped: " << nSkipped << " -> " << glfFile << std::endl;
+        if (!has("quiet") && nRePrepared) std::cout << "re-prepared behind late skips: " << nRePrepared << " windows" << std::endl;
         if (has("timing")) {
             const double wall = seconds_since(t_start);
             long peakKb = 0;                                                      // VmHWM of /proc/self/status

@@ -136,7 +136,7 @@ def concat(parts) -> PackedBatch:
     return PackedBatch(hap_var_flank=np.concatenate(flank), **{k: np.concatenate(v) for k, v in out.items()})
 
 
-def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_indel=12) -> PackedBatch:
+def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_indel=12, fix_reads=0, fix_read_len=0, fix_haps=0, trimmed=True) -> PackedBatch:
     """Windows in the shapes the reference's own pipeline produces (fixed seed; bench.py's `ragged` leg, tests):
 
     * reference haplotype = [minRef - 60, maxRef + 60] around the window's candidates (python/makeWindows.py:72-75): 121 bp for a
@@ -155,6 +155,9 @@ def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_in
         H = int(rng.integers(2, 13))
         R = int(np.exp(rng.uniform(np.log(20.0), np.log(float(max_reads)))))
         L = int(rng.choice([36, 76, 100, 150], p=[0.1, 0.25, 0.45, 0.2]))
+        if fix_reads: R = fix_reads                    # diagnostics (tools/ragged_factors.py): which kind of raggedness costs what
+        if fix_read_len: L = fix_read_len
+        if fix_haps: H = fix_haps
         parts.append(generate(1, H=H, R=R, L=L, hap_len=121 + extra, seed=int(rng.integers(1, 2 ** 31)), max_indel=int(rng.integers(1, max_indel + 1)),
-                              vary_read_len=(i % 5 == 4), mixed_quals=True))
+                              vary_read_len=(trimmed and i % 5 == 4), mixed_quals=True))
     return concat(parts)

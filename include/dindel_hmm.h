@@ -250,11 +250,12 @@ int dd_build_library_tables(const dd_batch *b, double *logprob_out, double *log9
 int dd_build_index(const dd_batch *b, int32_t *hap_window, int64_t *win_pair_off,
                    int64_t *win_hpos_off, int64_t *win_varcov_off);
 
-/* Ragged batches: every launch covers one (lane tiling of the haplotypes, read-length interval), so one long haplotype or read does not
- * put the whole batch on the slower build.  The haplotype classes are the lane tilings (<= 30, 62, 94, 126, 158, 190, 222, 254, 318, ... 766 bp);
- * the read intervals of a tiling are [1, T], (T, 160], (160, 1024] with T = the longest read whose back-pointer tile still fits LDS at full
- * occupancy for that tiling and these params (no such cut when p is NULL).  A haplotype is listed in a launch only if its window holds a
- * read of the interval.  dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the summary once on the host
+/* Ragged batches: every launch covers one (lane tiling of the haplotypes, read class), so one long haplotype or read does not put the
+ * whole batch on the slower build.  The haplotype classes are the lane tilings (<= 30, 62, 94, 126, 158, 190, 222, 254, 318, ... 766 bp).
+ * Read classes of a tiling: 0 = the reads of windows whose longest read (up to 160 bp) is <= T, 1 = the reads up to 160 bp of the other
+ * windows, 2 = reads longer than 160 bp; T = the longest read whose back-pointer tile still fits LDS at full occupancy for that tiling and
+ * these params (no class 0 / 1 distinction when p is NULL).  A haplotype is listed in a launch only if its window has reads for it.
+ * dd_compute_likelihoods does this by itself; for dd_launch_device the caller builds the summary once on the host
  * (dd_build_length_classes), uploads hap_class_list and hands both over in dd_device_batch. */
 #define DD_N_HAP_CLASSES 16
 #define DD_N_READ_CLASSES 3
@@ -264,6 +265,7 @@ typedef struct dd_launch_class {
     int32_t max_hap_len;                /* longest haplotype of the list                                                                  */
     int32_t min_read_len, max_read_len; /* shortest admissible read / longest read present                                                */
     int32_t max_window_reads, avg_window_reads;   /* reads of the interval per window of the list: most, mean                             */
+    int32_t avg_read_len;               /* mean length of those reads                                                                      */
 } dd_launch_class;
 typedef struct dd_length_classes {
     int32_t n_launches;                 /* non-empty (tiling, interval) combinations                                                      */
@@ -364,8 +366,10 @@ void dd_last_launch(int32_t out[8]);
  * the number of launches is returned.  Record: {K positions per lane, pairs per wavefront (1, or 2 on 32-lane halves), D build,
  * 1 = back-pointers in HBM scratch, 1 = FOLD build, waves per workgroup, LDS bytes per workgroup, grid, read split, haplotypes covered,
  * longest haplotype of the class, shortest admissible read, longest read of the class, waves per CU the plan expects, occupancy variant,
- * duration in microseconds (-1 unless the process runs with DD_LAUNCH_TIMING=1: diagnostics, the read-out synchronises)}. */
-#define DD_LAUNCH_LOG_FIELDS 16
+ * duration in microseconds (-1 unless the process runs with DD_LAUNCH_TIMING=1: diagnostics, the read-out synchronises),
+ * 1 = persistent grid drawing its items from a counter (ragged launches), reads per wavefront a haplotype's workgroups are sized for (0 = the
+ * launch's read split for every haplotype)}. */
+#define DD_LAUNCH_LOG_FIELDS 18
 int dd_launch_log(int32_t *out, int max_records);
 /* How many output arrays of the last dd_compute_likelihoods / _faster call on this host thread were written by the kernels directly
  * into the caller's memory: arrays that lie in page-locked, device-addressable host memory (dd_host_alloc, hipHostMalloc) are

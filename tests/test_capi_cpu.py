@@ -229,9 +229,9 @@ def test_length_classes_and_library_tables_on_the_host(lib):
         assert (r >= L.min_read_len).all() and L.max_read_len == int(r.max()) and L.max_window_reads == L.avg_window_reads == 1
         seen += seg.tolist()
     assert sorted(seen) == list(range(pb.n_haps))
-    # read intervals: [1, T] (back-pointer tile in LDS at full occupancy: plan without HBM scratch), (T, 160], (160, 1024]
+    # read classes: windows whose longest read is <= T (back-pointer tile in LDS at full occupancy), the other windows' reads up to 160 bp, reads > 160 bp
     k2 = [L for L in launches if L.hap_class == 3]                           # 95..126 bp: the (126, 161) window and the shorter haplotype of (127, 160)
-    assert [(L.max_read_len, L.list_len) for L in k2] == [(160, 1), (161, 2)] and k2[1].min_read_len == 161 and 100 < k2[0].min_read_len <= 160
+    assert [(L.max_read_len, L.list_len) for L in k2] == [(160, 1), (161, 2)] and k2[1].min_read_len == 161 and k2[0].min_read_len == 1
     k1 = [L for L in launches if L.hap_class == 1]                           # 31..62 bp: (50, 36), (62, 100) and the shorter haplotype of (63, 100)
     assert [(L.min_read_len, L.max_read_len, L.list_len) for L in k1] == [(1, 100, 5)]
     # without params there is no cut at T: [1, 160], (160, 1024]

@@ -106,3 +106,32 @@ def test_reference_exit_paths_end_the_run(tmp_path):
     r = subprocess.run([DRIVER, "--bamFile", bam, "--varFile", vf, "--hapFile", hf, "--outputFile", str(tmp_path / "o"), "--prepareOnly", "--quiet"],
                        env=_env(), capture_output=True, text=True)
     assert r.returncode == 1 and "matepos inconsistency!" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_late_skip_re_prepares_the_windows_behind_it(tmp_path):
+    """A window skipped AFTER read selection (the likelihood or genotyping step threw: "hapSize error.", DInDel.cpp:1369-1408) empties the
+    reference's read buffer for the window behind it (:1404-1405); with several pools that changes the ORDER of the buffer, hence of the reads
+    inside a mapping-quality tie.  The prepare workers run ahead of that knowledge; the writer re-prepares the windows in reach.  Truth =
+    the same run with the late skips announced to the prepare stage (--lateSkipsKnown: buffers reset behind them, window by window on one
+    worker); the pipeline cut into batches any way must hand the same reads in the same order to every window and write the same bytes."""
+    if not os.path.exists(DRIVER):
+        pytest.skip("dindel_gpu not built")
+    s = _scene(tmp_path)
+    inject = "4,9,10,23,%d,%d" % (s["n"] // 2, s["n"])                      # single ones, two in a row, the last window of the file
+    late = ["--injectLateSkip", inject]
+    plain = _dumps(tmp_path, "plain", s, ["--bamFiles", s["list"]], ["--batchWindows", "100000", "--prepareThreads", "1"])
+    truth = _dumps(tmp_path, "truth", s, ["--bamFiles", s["list"]], late + ["--lateSkipsKnown", "--batchWindows", "100000", "--prepareThreads", "1"])
+    glf_truth = open(str(tmp_path / "truth" / "out.glf.txt")).read()
+    assert glf_truth.count("error_hapSize_error.") == 6
+    # the reset matters: behind the injected windows some window gets the same reads in another order
+    reordered = [i for i in range(s["n"]) if plain[i] != truth[i]]
+    assert reordered and all(sorted(plain[i].split("\n")) == sorted(truth[i].split("\n")) for i in reordered)
+    for batch, threads in ((100000, 1), (3, 4), (1, 3), (17, 2)):
+        tag = "late%d" % batch
+        got = _dumps(tmp_path, tag, s, ["--bamFiles", s["list"]], late + ["--batchWindows", str(batch), "--prepareThreads", str(threads)])
+        assert got == truth, "batches of %d windows" % batch
+        assert open(str(tmp_path / tag / "out.glf.txt")).read() == glf_truth
+    # one pool: a reset does not change what a window sees, and nothing is re-prepared
+    one = _dumps(tmp_path, "one_late", s, ["--bamFile", s["paths"][0]], late + ["--batchWindows", "5", "--prepareThreads", "3"])
+    one_plain = _dumps(tmp_path, "one_plain", s, ["--bamFile", s["paths"][0]], ["--batchWindows", "5", "--prepareThreads", "3"])
+    assert one == one_plain
