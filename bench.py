@@ -221,6 +221,14 @@ def ragged_leg(params, device, windows=2400, steps=3):
             ci = int(np.searchsorted(capi.HAP_CLASS_BOUNDS, rec["max_hap"], side="left"))    # the launch's lane tiling = haplotype-length class
             hsel = (hl > (capi.HAP_CLASS_BOUNDS[ci - 1] if ci else 0)) & (hl <= capi.HAP_CLASS_BOUNDS[ci])
             rsel = (rl >= rec["min_read"]) & (rl <= rec["max_read"])
+            # read classes 0 / 1 of a tiling split the WINDOWS by their longest read up to 160 bp (capi.cpp build_launch_classes): a launch
+            # that starts at 1 bp owns the windows whose longest such read is above the longest read of the tiling's shorter launch
+            ci_of = lambda mh: int(np.searchsorted(capi.HAP_CLASS_BOUNDS, mh, side="left"))
+            below = [q["max_read"] for q in log if ci_of(q["max_hap"]) == ci and q["min_read"] == 1 and q["max_read"] < rec["max_read"]]
+            wmax = np.zeros(pb.n_windows, np.int64)
+            np.maximum.at(wmax, rw[rl <= 160], rl[rl <= 160])
+            if rec["min_read"] == 1:
+                rsel &= (wmax[rw] > (max(below) if below else 0)) & (wmax[rw] <= rec["max_read"])
             rsum = np.bincount(rw[rsel], weights=rl[rsel], minlength=pb.n_windows)
             cells = float((hl[hsel] * rsum[hw[hsel]]).sum())
             pos = 64 * rec["K"] // rec["pairs_per_wave"]
@@ -246,9 +254,13 @@ def in_process_leg(pb, params, world, devices, dev, args):
     leg never takes the headline down: an error is reported in the line instead."""
     try:
         import ctypes as C
-        from dindel_tgi_amd.batch import alloc_result
+        from dindel_tgi_amd.batch import RESULT_DTYPES, alloc_result, result_lengths
         lib = capi.load()
-        big = synth.tile(pb, world)
+        # host memory of the leg: the tiled batch and its (pageable) result arrays, ~0.41 MB per configs[1] window — rank 0 keeps it
+        # under --in-process-gib (default 8): at N = 8 that is 2,400 windows per device instead of 10,000 (32 GB)
+        per_window = (sum(np.dtype(RESULT_DTYPES[k]).itemsize * n for k, n in result_lengths(pb).items()) + pb.read_bases * 2 + pb.hap_bases) / max(pb.n_windows, 1)
+        per_dev = int(max(1, min(pb.n_windows, args.in_process_gib * 2 ** 30 / per_window / world)))
+        big = synth.tile(pb if per_dev == pb.n_windows else pb.slice_windows(0, per_dev), world)
         arrs, res = alloc_result(big)
         hb = big.ctypes_batch()
         devs = (C.c_int32 * len(devices))(*devices)
@@ -259,13 +271,14 @@ def in_process_leg(pb, params, world, devices, dev, args):
             dt = time.perf_counter() - t0
             if rc != 0:
                 return {"error": "dd_compute_likelihoods_multi rc=%d: %s" % (rc, capi.last_error())}
-        n = pb.n_pairs                              # block 0 of the tiled batch is rank 0's own batch: same numbers as its resident launch
+        n = int(big.n_pairs // world)               # block 0 of the tiled batch is (the front of) rank 0's own batch: same numbers as its resident launch
         same = bool(np.array_equal(arrs["ll"][:n], dev.out["ll"][:n].cpu().numpy())) and bool((arrs["status"][:big.n_pairs] == 0).all())
+        host_gib = sum(a.nbytes for a in arrs.values()) / 2 ** 30
         lib.dd_release_cache()
         return {"what": "dd_compute_likelihoods_multi(devices=%s) on %d windows held in (pageable) host memory: one process, one host thread per "
                         "device, contiguous window blocks, no collective; H2D + kernels + D2H of every output" % (list(devices), big.n_windows),
                 "seconds": dt, "cells_per_s": big.cells / dt, "windows_per_s": big.n_windows / dt, "devices": list(devices),
-                "equals_resident_launch": same}
+                "windows_per_device": per_dev, "host_result_gib": host_gib, "equals_resident_launch": same}
     except Exception as e:                          # noqa: BLE001
         return {"error": repr(e)[:400]}
 
@@ -324,6 +337,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-window-loop", action="store_true", help="skip the BAM -> .glf.txt window-loop leg (N=1)")
     ap.add_argument("--no-ragged", action="store_true", help="skip the real-shaped (ragged) batch leg (N=1)")
+    ap.add_argument("--ragged-only", action="store_true",
+                    help="N=1: time only the real-shaped batch (--steps launches of it) and print its JSON — for rocprofv3 runs of that leg's kernels")
+    ap.add_argument("--ragged-windows", type=int, default=2400)
     ap.add_argument("--host-api", action="store_true", help="(kept for old command lines: the host-API legs now run by default at N=1)")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the legs beside the headline figure: at N=1 the host API (copies included) and the C++ adapter end to end, "
@@ -335,6 +351,8 @@ def main():
                     help="N>1: size of the job whose single strong-scaling pass is reported under `configs3` (0 = skip)")
     ap.add_argument("--max-batch-windows", type=int, default=50000,
                     help="strong scaling: largest sub-batch a rank keeps resident (a batch holds < 2^31 read bases)")
+    ap.add_argument("--in-process-gib", type=float, default=8.0,
+                    help="N>1: host memory (GiB) the one-process leg's tiled batch and result arrays may take on rank 0")
     ap.add_argument("--faster", action="store_true",
                     help="time the secondary --faster model (ObservationModelS, SURVEY row A13) instead of the headline path; "
                          "the JSON line then names that model in `metric` and is not the BASELINE metric")
@@ -352,6 +370,14 @@ def main():
     if args.rehearse:
         local_rank = 0
     host_group = None
+    cpu_base = None
+    if world > 1 and rank == 0 and not args.no_cpu_baseline and not args.rehearse and args.total_windows == 0:
+        # the CPU baseline belongs in the N > 1 line too (a SCALE record without it is incomplete): rank 0 times it BEFORE the process
+        # group exists — the other ranks wait in the rendezvous meanwhile, no collective kernel spins on their GPUs
+        p0 = capi.params_cli_defaults()
+        p0.maxLengthDel = args.max_length_del
+        cpu_base = cpu_baseline(synth.generate(min(args.windows, 400), H=args.haps, R=args.reads, L=args.read_len, hap_len=args.hap_len, seed=0x9E3779B9),
+                                p0, faster=args.faster)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:
@@ -368,6 +394,11 @@ def main():
 
     params = capi.params_cli_defaults()
     params.maxLengthDel = args.max_length_del
+    if args.ragged_only:
+        assert world == 1, "--ragged-only is an N=1 leg"
+        print(json.dumps({"metric": "read-haplotype HMM cells/s, real-shaped (ragged) batch", "unit": "cells/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+                          **ragged_leg(params, device, windows=args.ragged_windows, steps=max(args.steps, 1))}))
+        return
     # rank r owns windows [r*W, (r+1)*W) of the job; its block is generated from seed+r
     strong = args.total_windows > 0
     if strong:
@@ -555,9 +586,11 @@ def main():
             if not args.no_window_loop:
                 out["window_loop"] = window_loop_leg(args.faster)
         if world == 1 and not strong and not args.no_ragged and not args.faster:
-            out["ragged"] = ragged_leg(params, device)
-        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would idle in the collective teardown)
+            out["ragged"] = ragged_leg(params, device, windows=args.ragged_windows)
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pb, params, faster=args.faster)
+        elif cpu_base is not None:                        # N > 1: timed by rank 0 before the ranks met (see above)
+            out["cpu_baseline"] = cpu_base
         if args.faster:
             out["metric"] = "read-haplotype cells/s, --faster model (ObservationModelS)"
             out["roofline"]["kernel"] = "dd_faster_kernel"

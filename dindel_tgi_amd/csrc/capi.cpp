@@ -66,12 +66,14 @@ int hap_class_of(int hap_len)
     return -1;
 }
 // tiling for a launch whose longest haplotype is max_hap_len: false if it is too long
-bool pick_tiling(int max_hap_len, int &G, int &K)
+bool pick_tiling(int max_hap_len, int Dt, int &G, int &K)
 {
     const int c = hap_class_of(max_hap_len);
     if (c < 0) return false;
     G = kHapClasses[c].G; K = kHapClasses[c].K;
-    if (G > 1 && half_wave_off()) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
+    // K = 7 halves only on the D = 6 build: at D = 11 / 12 the sweep's register need halves its rate (1.26e11 against 2.09e11 cells/s on a
+    // whole wavefront at 200 bp, maxLengthDel 10; the other half tilings gain 9-16 % there too: profiles/r04/tiling_sweep_mld10.jsonl)
+    if (G > 1 && (half_wave_off() || (K == 7 && Dt > 7))) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
     return true;
 }
 
@@ -151,7 +153,8 @@ static const size_t DD_WS_HEADER = 256;
 // beta[bMid] waits for the join (hmm_kernel.hip STASH)
 size_t scratch_wave_bytes(int K, int Dt, int G, int max_read_len)
 {
-    return (size_t)max_read_len * 64u * bt_word_bytes(K, Dt) + ((K >= 3 || G > 1) ? (size_t)2 * K * 64 * 8 : 0);
+    const bool slim = G > 1 || K == 3 || K == 5 || (K == 4 && Dt <= 7);       // hmm_kernel.hip SLIM
+    return (size_t)max_read_len * 64u * bt_word_bytes(K, Dt) + (slim ? (size_t)2 * K * 64 * 8 : 0);
 }
 
 // Launch plan: LDS-resident back-pointers when that keeps the CU as full as the registers allow, otherwise
@@ -168,7 +171,7 @@ struct Plan {
 int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, Plan &pl, ddk::KernelArgs &A)
 {
     pl.Dt = pick_Dt(p->maxLengthDel + 1);
-    if (!pick_tiling(max_hap_len, pl.G, pl.K)) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
+    if (!pick_tiling(max_hap_len, pl.Dt, pl.G, pl.K)) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
     int best[2] = {0, 0}, bw[2] = {0, 0}, cap[2] = {0, 0};
     for (int gbt = 0; gbt < 2; gbt++) {
         const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0, pl.G);

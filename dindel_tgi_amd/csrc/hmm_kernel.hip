@@ -203,7 +203,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // positions per lane of a half, so a pair costs K / 2 lane-positions per read base instead of ceil((Hs + 2) / 64): haplotypes of
 // 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves, <= 30 bp as K = 1 halves (capi.cpp kHapClasses).
 // The two reads advance base by base together (their trip counts are padded to the longer one, the shorter one's lanes masked off), so
-// the workgroup first orders the window's reads by (bMid, bases right of bMid) and a wavefront takes two consecutive ranks.  Every
+// the workgroup first orders the window's reads by (length, bMid) and a wavefront takes two consecutive ranks.  Every
 // per-read quantity that the G = 1 build keeps on the scalar unit is a per-lane value here, equal across the lanes of a half.
 template <int K, int D, bool GBT, bool FOLD = false, int OCC = 0, int G = 1>
 __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SIMD(K, D, GBT, G)) dd_hmm_kernel(const KernelArgs P)
@@ -257,7 +257,9 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // 8-byte store / load per position per read — an LDS row for it cost the K = 5 builds two of their eight waves per CU), and with two pairs per wavefront the per-read addresses are formed again
     // after the sweeps instead of being carried through them.  (Round 4: the K = 5 half-wave build spilled 59 registers, 5 scratch
     // accesses inside the right->middle sweep, without this.)
-    constexpr bool SLIM = (K >= 3) || (G > 1);
+    // Which builds: the ones measured to gain or hold (tools/plan_check.py against round 3, profiles/r04): K = 3, K = 5, K = 4 at D <= 7 and every
+    // half-wave build; K = 4 at D > 7 and K >= 6 (1 wave per SIMD, registers to spare) lost 3-7 % to the reloads and keep the round-3 form.
+    constexpr bool SLIM = (G > 1) || K == 3 || K == 5 || (K == 4 && D <= 7);
     constexpr bool STASH = SLIM && GBT;            // beta[bMid] parked behind the wave's back-pointer tile in the HBM scratch: [2 K][64] doubles
     double *shC = reinterpret_cast<double *>(smem + P.lds_off_C);  // LEAN: [K*D][W] lp_y(src)+Nn[src]
     double *shY = reinterpret_cast<double *>(smem + P.lds_off_Y);  // LEAN: [D] (y-1)*II
@@ -507,7 +509,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // ======================= loop over this wave's reads =======================
     // The haplotype's workgroups share its reads in contiguous blocks; inside a workgroup the wavefronts pull the next read from a counter
     // in LDS when they are free.  G = 2: the window's reads are taken in chunks of DD_HALF_CHUNK; every workgroup of the haplotype orders
-    // the chunk's reads of this launch's length class by (bMid, L) — the two pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) +
+    // the chunk's reads of this launch's length class by (L, bMid) — the two pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) +
     // max(bMid1, bMid2) sweeps, so they should agree in both — and a pull takes two consecutive ranks.  Results do not depend on the order.
     const int nChunks = (G == 1) ? 1 : (R + DD_HALF_CHUNK - 1) / DD_HALF_CHUNK;
     for (int chunk0 = 0, ci = 0; ci < nChunks; ci++, chunk0 += DD_HALF_CHUNK) {
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             uint32_t key = 0xffffffffu;            // not of this launch's length class: behind every read that is
             if (L >= P.len_min && L <= P.len_max) {
                 if (!hap_ok) { if (split == 0) mark_hapsize(chunk0 + t, 0, 1); }
-                else key = ((uint32_t)bmid_of(rr, L) << 11) | (uint32_t)((L - 1) & 2047);
+                else key = ((uint32_t)((L - 1) & 2047) << 11) | (uint32_t)bmid_of(rr, L);   // length first: both trip counts follow it
             }
             skey[t] = key;
         }
@@ -635,7 +637,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             auto cinc = [&](int k, int y) -> double {       // y = 1..D
                 if constexpr (LEAN) return shC[(k * D + y - 1) * W + lane]; else return cInc[k][y - 1];
             };
-            auto incStep = [&](const int b) __attribute__((always_inline)) {
+            // G = 2: both pairs run the longer pair's trip count, the lanes of the pair that is done wait masked.  (One loop for both forms,
+            // no lambda for the body: with the body in a lambda the K = 2 / D = 11 scratch build spilled 38 registers instead of 6.)
+            for (int it = 0, b = L - 1; (G == 1) ? (b > bMid) : (it < nIncW); it++, b--) {
+                if (G == 1 || it < nInc) {
                 const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
                 const int col = rdC[b];
                 double v[D + K], ov[D + K];
@@ -729,12 +734,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
                 bt[b * 64 + wlane] = word;                          // btb[b-1] stored at row b
-            };
-            if constexpr (G == 1) {
-                for (int b = L - 1; b > bMid; b--) incStep(b);
-            } else {
-                for (int it = 0; it < nIncW; it++)
-                    if (it < nInc) incStep(L - 1 - it);
+                }
             }
         }
         STAMP(3);   // Inc passes
@@ -781,7 +781,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     for (int y = 2; y <= D; y++) lpDec[k][y - 1] = (y > Dr) ? NEG_INF : eIn[k] + (double)(y - 1) * II;
                 }
             }
-            auto decStep = [&](const int b) __attribute__((always_inline)) {
+            for (int b = 1; (G == 1) ? (b <= bMid) : (b <= nDecW); b++) {
+                if (G == 1 || b <= nDec) {
                 const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
                 const int col = rdC[b - 1];
                 double v[D + K], ov[D + K];
@@ -872,12 +873,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     word |= (D <= 7) ? (btword_t)btb[k] : (btword_t)((btword_t)btb[k] << (k * BP::PB));
                 }
                 bt[b * 64 + wlane] = word;
-            };
-            if constexpr (G == 1) {
-                for (int b = 1; b <= bMid; b++) decStep(b);
-            } else {
-                for (int it = 1; it <= nDecW; it++)
-                    if (it <= nDec) decStep(it);
+                }
             }
         }
         STAMP(2);   // Dec passes
@@ -1335,7 +1331,7 @@ static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, 
     case 1: return launch_one<1, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 3: return launch_one<3, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 5: return launch_one<5, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
-    case 7: return launch_one<7, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
+    case 7: if constexpr (D == 6) return launch_one<7, D, GBT, false, 0, 2>(A, grid, waves, lds, st); else return hipErrorInvalidValue;   // (capi.cpp pick_tiling)
     default: return hipErrorInvalidValue;
     }
 }

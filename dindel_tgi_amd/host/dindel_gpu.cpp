@@ -37,6 +37,8 @@
 //                     pair (DInDel.cpp:589-620; main model only, like the reference; the haplotype file needs its A records)
 //   [--timing]        one "timing:" line on stdout with the busy time of each stage
 //   [--prepareOnly]   stop after the prepare stage (no likelihoods, no calls: profiling the read selection on a GPU-less host)
+//   [--windowByWindow] tests: the writer re-does every window one after the other with a read buffer of its own (the reference's loop as it stands)
+//   [--windowByWindow] tests: the writer re-does every window one after the other with a read buffer of its own (the reference's loop as it stands)
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -199,7 +201,7 @@ int main(int argc, char **argv)
         if (a.compare(0, 2, "--") != 0) { std::cerr << "Unknown argument " << a << "\n"; return 2; }
         a = a.substr(2);
         if (a == "varFileIsOneBased" || a == "faster" || a == "filterHaplotypes" || a == "quiet" || a == "doDiploid" || a == "timing" || a == "outputRealignedBAM" ||
-            a == "prepareOnly" || a == "noLookBack" || a == "lateSkipsKnown") opt[a] = "1";
+            a == "prepareOnly" || a == "noLookBack" || a == "lateSkipsKnown" || a == "windowByWindow") opt[a] = "1";
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { std::cerr << "Option --" << a << " needs a value\n"; return 2; }
     }
@@ -289,6 +291,9 @@ int main(int argc, char **argv)
             }
         }
         const bool lateSkipsKnown = has("lateSkipsKnown");
+        // --windowByWindow (tests, diagnostics): the writer re-does EVERY window — read selection from its own buffer, likelihoods, genotyping —
+        // one after the other, i.e. the reference's loop as it stands (DInDel.cpp:1310-1411); what the pipeline prepared ahead is ignored
+        const bool windowByWindow = has("windowByWindow");
 
         const std::string outputPrefix = opt["outputFile"];
         const char *dumpReads = getenv("DINDEL_DUMP_READS");                       // diagnostics: what each window hands to the likelihood step
@@ -567,12 +572,15 @@ int main(int argc, char **argv)
                     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
                     for (size_t i = 0; i < B.tasks.size(); i++) {
                         WindowTask &T = B.tasks[i];
-                        if (redo.active) {
+                        if (windowByWindow) {
+                            if (T.tid != redo.tid || !redo.fetcher) { redo.first = true; redo.tid = T.tid; }     // DInDel.cpp:1327-1333
+                            rePrepare(T);
+                        } else if (redo.active) {
                             // (a new chromosome resets the buffer in both histories; beyond `reach` no record of the reset's moment is left)
                             if ((redo.first && T.tid != redo.tid) || (!redo.first && (T.tid != redo.tid || uint64_t(T.fileLeftPos) >= redo.reach))) redo.active = false;
                             else rePrepare(T);
                         }
-                        if (T.lateSkip && pooled && !lateSkipsKnown) { redo.active = true; redo.first = true; redo.tid = T.tid; }
+                        if (T.lateSkip && pooled && !lateSkipsKnown && !windowByWindow) { redo.active = true; redo.first = true; redo.tid = T.tid; }
                         if (T.skipped) {
                             std::cerr << "skipped " << T.tid << " " << T.pos << " reason: " << T.message << std::endl;     // DInDel.cpp:1383
                             nSkipped++;

@@ -42,7 +42,7 @@ while time.time() < t_end:
     if rng.random() < 0.15:
         p.bMid = int(rng.integers(0, 30))
     if kind == 0:
-        max_hap = int(rng.choice([40, 62, 126, 190, 254, 400, 755]))   # make_windows adds up to 7 inserted bases
+        max_hap = int(rng.choice([23, 40, 62, 87, 126, 151, 190, 215, 254, 400, 755]))   # make_windows adds up to 7 inserted bases; every lane tiling incl. the half-wave ones
         ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1,
                           with_vars=bool(rng.random() < 0.6))
         libs = None

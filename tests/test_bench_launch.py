@@ -36,6 +36,20 @@ def test_plain_launch_starts_two_ranks_cpu():
     assert row["value"] is None and "launch-only" in row["rehearsal"]
 
 
+def test_plain_launch_starts_eight_ranks_cpu():
+    """The rank count the driver's scaling run uses: launcher, rendezvous and the gather layout with 8 ranks (launch-only: no GPU here)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("launch-only rehearsal: needs a host without GPU")
+    env = _env()
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearse", "--windows", "6", "--haps", "2", "--reads", "5"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    row = _json_line(r.stdout)
+    assert row["n_gpus"] == 8 and row["ranks"] == 8 and row["backend"] == "gloo" and row["value"] is None
+
+
 def test_world_size_must_equal_gpus():
     env = _env()
     env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")

@@ -180,6 +180,7 @@ def test_launch_plan_rules(lib, monkeypatch):
     monkeypatch.setenv("DD_NO_HALF", "1")                      # A/B switch: whole-wavefront tilings only
     assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in (30, 62, 63, 127, 191, 222)] == [(1, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 4)]
     monkeypatch.delenv("DD_NO_HALF")
+    assert [(plan(hap=h, mld=10)["G"], plan(hap=h, mld=10)["K"]) for h in (30, 94, 158, 222)] == [(2, 1), (2, 3), (2, 5), (1, 4)]   # K = 7 halves: D = 6 build only
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6

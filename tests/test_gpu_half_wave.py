@@ -42,6 +42,10 @@ def test_half_wave_builds_equal_oracle_and_whole_wave_builds(lib, monkeypatch, h
         p.maxLengthDel = mld
         got = run_host_api(lib, p, pb)
         log = capi.launch_log()
+        if HALF_K[hs] == 7 and mld > 5:                                  # K = 7 halves: the D = 6 build only
+            assert all(r["pairs_per_wave"] == 1 for r in log), log
+            assert_same(got, _oracle.batch(p, pb, nthreads=8), pb)
+            continue
         assert any(r["pairs_per_wave"] == 2 and r["K"] == HALF_K[hs] for r in log), log
         want = _oracle.batch(p, pb, nthreads=8)
         assert_same(got, want, pb)
@@ -84,7 +88,7 @@ def test_half_wave_hapsize_error_and_empty_windows(lib):
 
 def test_half_wave_fuzz_with_variants_and_mates(lib):
     from tests.test_gpu_fuzz import make_windows
-    for seed, max_hap, mld in ((1, 94, 5), (2, 158, 5), (3, 158, 10), (4, 30, 3), (5, 222, 7)):
+    for seed, max_hap, mld in ((1, 94, 5), (2, 158, 5), (3, 158, 10), (4, 30, 3), (5, 222, 4)):
         rng = np.random.default_rng(7000 + seed)
         ws = make_windows(rng, 60, max_hap, 120, min_hap=max(mld, 1), with_vars=True)
         p = capi.params_cli_defaults()

@@ -23,14 +23,16 @@ def params():
 @pytest.mark.parametrize("hap_len", [120, 160, 200])
 def test_stress_shape_against_oracle(hap_len):
     """16 haplotypes x 24 reads of 250 bp x 3 windows per haplotype length: 1,152 pairs of ~3.5e4 cells each, every output
-    equal to the oracle's (HBM-scratch builds of the D = 11 kernel: K = 2, K = 3 and — 191..222 bp — two pairs per wavefront at K = 7)."""
+    equal to the oracle's (HBM-scratch builds of the D = 11 kernel: K = 2, two pairs per wavefront at K = 5 (127..158 bp), K = 4)."""
     pb = synth.generate(3, H=16, R=24, L=250, hap_len=hap_len, seed=1000 + hap_len, max_indel=3, mixed_quals=True)
     p = params()
     dev = DeviceBatch(pb, p, "cuda:0")
     dev.launch()
     torch.cuda.synchronize()
     g = capi.last_launch()
-    _, G, K = next(c for c in capi.HAP_CLASSES if pb.max_hap_len <= c[0])                              # lane tiling of the longest haplotype
+    bound, G, K = next(c for c in capi.HAP_CLASSES if pb.max_hap_len <= c[0])                          # lane tiling of the longest haplotype
+    if K == 7:                                                                                      # (K = 7 halves run on the D = 6 build only)
+        G, K = 1, (bound + 2 + 63) // 64
     assert g["D"] % 100 == 11 and g["K"] == K and g["D"] >= 100                                     # D = 11 build, back-pointers in HBM scratch
     assert capi.launch_log()[-1]["pairs_per_wave"] == G
     assert_same(dev.results(), _oracle.batch(p, pb, nthreads=16), pb)

@@ -419,3 +419,41 @@ def test_window_loop_calls_the_simulated_variants(tmp_path):
     last = [json.loads(l) for l in r.stdout.split("\n") if l.startswith("{")][-1]
     assert last["step"] == "glf2vcf" and last["windows"] == 500, r.stdout + r.stderr
     assert last["true_variant_called"] >= 485 and last["called_heterozygous"] == last["true_variant_called"] and last["vcf_records"] <= 510
+
+
+def test_late_skip_with_two_pools_is_re_prepared(tmp_path):
+    """--bamFiles with two pools and windows whose likelihood step throws ("hapSize error.": a 2-bp haplotype against maxLengthDel 5): the
+    reference empties its read buffer behind such a window (DInDel.cpp:1404-1405), which changes the order of the next windows' reads inside
+    mapping-quality ties.  The pipeline, which prepared those windows ahead, must write what the loop run window by window writes
+    (--windowByWindow: the writer redoes every window itself, one after the other), and hand the same reads in the same order to every window."""
+    from tests.test_n2_pools_cpu import DRIVER, _env, _scene
+    s = _scene(tmp_path, n_ref=60000, n_reads=16000)
+    bad = (4, 9, 10, s["n"] // 2)
+    lines = open(s["hf"]).read().split("\n")
+    out, w = [], 0
+    for ln in lines:                                       # the first haplotype of the chosen windows becomes 2 bp long
+        if ln.startswith("W "):
+            w = int(ln.split()[1])
+            first = True
+        if ln.startswith("H ") and w in bad and first:
+            ln, first = "H AC", False
+        elif ln.startswith("H "):
+            first = False
+        out.append(ln)
+    open(s["hf"], "w").write("\n".join(out))
+
+    def run(tag, *extra):
+        d = tmp_path / tag
+        d.mkdir()
+        env = _env()
+        env["DINDEL_DUMP_READS"] = str(d / "w")
+        r = subprocess.run([DRIVER, "--bamFiles", s["list"], "--varFile", s["vf"], "--hapFile", s["hf"], "--outputFile", str(d / "out")] + list(extra),
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(str(d / "out.glf.txt")).read(), [open(str(d / ("w.%d" % (i + 1)))).read() for i in range(s["n"])], r.stdout
+    glf_truth, dumps_truth, _ = run("wbw", "--windowByWindow", "--batchWindows", "16", "--prepareThreads", "2")
+    assert glf_truth.count("error_hapSize_error.") == len(bad)
+    for batch, threads in ((5, 3), (64, 2)):
+        glf, dumps, stdout = run("b%d" % batch, "--batchWindows", str(batch), "--prepareThreads", str(threads))
+        assert "re-prepared behind late skips" in stdout
+        assert dumps == dumps_truth and glf == glf_truth, "batches of %d windows" % batch

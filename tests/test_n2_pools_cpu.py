@@ -126,6 +126,9 @@ def test_late_skip_re_prepares_the_windows_behind_it(tmp_path):
     # the reset matters: behind the injected windows some window gets the same reads in another order
     reordered = [i for i in range(s["n"]) if plain[i] != truth[i]]
     assert reordered and all(sorted(plain[i].split("\n")) == sorted(truth[i].split("\n")) for i in reordered)
+    # a second, independent truth: the writer redoing every window one after the other (--windowByWindow: the reference's loop as it stands)
+    wbw = _dumps(tmp_path, "wbw", s, ["--bamFiles", s["list"]], late + ["--windowByWindow", "--batchWindows", "7", "--prepareThreads", "2"])
+    assert wbw == truth and open(str(tmp_path / "wbw" / "out.glf.txt")).read() == glf_truth
     for batch, threads in ((100000, 1), (3, 4), (1, 3), (17, 2)):
         tag = "late%d" % batch
         got = _dumps(tmp_path, tag, s, ["--bamFiles", s["list"]], late + ["--batchWindows", str(batch), "--prepareThreads", str(threads)])
