@@ -102,7 +102,7 @@ class dd_device_batch(C.Structure):
 
 
 # haplotype-length classes of a ragged batch, one per lane tiling (capi.cpp kHapClasses): longest haplotype, pairs per wavefront, positions per lane
-HAP_CLASSES = [(30, 2, 1), (62, 1, 1), (94, 2, 3), (126, 1, 2), (158, 2, 5), (190, 1, 3), (222, 2, 7), (254, 1, 4), (318, 1, 5), (382, 1, 6),
+HAP_CLASSES = [(30, 2, 1), (62, 1, 1), (94, 2, 3), (126, 1, 2), (158, 2, 5), (190, 1, 3), (222, 1, 4), (254, 1, 4), (318, 1, 5), (382, 1, 6),
                (446, 1, 7), (510, 1, 8), (574, 1, 9), (638, 1, 10), (702, 1, 11), (766, 1, 12)]
 HAP_CLASS_BOUNDS = [c[0] for c in HAP_CLASSES]
 

@@ -50,13 +50,16 @@ double hp_error(int hpLen)
 // Lane tilings, by haplotype length.  numS = Hs + 2 states go over the 64 lanes of a wavefront, K positions per lane (every K = 1..12 is
 // instantiated, so no shape pays for more than 63 positions it does not have) — or, round 4, over the 32 lanes of HALF a wavefront, two
 // pairs side by side (G = 2), where 32 K is the tighter fit: 127..158 bp run as K = 5 halves (2.5 lane-positions per pair instead of 3),
-// 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves (3.5 instead of 4), <= 30 bp as K = 1 halves (0.5 instead of 1).
+// 63..94 bp as K = 3 halves (1.5 instead of 2), <= 30 bp as K = 1 halves (0.5 instead of 1).
 // Measured against the whole-wavefront tilings (tools/tiling_sweep.py, profiles/r04/tiling_sweep*.jsonl; 8 x 200 reads of 100 bp): <= 30 bp
-// x 1.8, 63..94 bp + 2-4 %, 127..158 bp + 14-16 %, 191..222 bp + 9-11 %; 31..62 bp as K = 2 halves were level with K = 1 on a whole
-// wavefront (its FOLD build), so that class stays there.
+// x 1.8, 63..94 bp + 1-7 %, 127..158 bp + 14-18 % (+ 4-9 % in ragged batches whose reads differ in length inside a window: the two reads
+// of a wavefront run the longer one's trip counts).  31..62 bp as K = 2 halves were level with K = 1 on a whole wavefront (its FOLD build)
+// and 191..222 bp as K = 7 halves gained 4-10 % on uniform windows of 100-bp reads but LOST 26-33 % on ragged ones with 150-bp reads (their
+// LDS rows leave a CU 6 wavefronts, profiles/r04/wide_sample_ab.jsonl): both classes stay on a whole wavefront (the 191..222-bp class keeps
+// its own launch: K = 4 like its neighbour).
 struct HapClassDef { int bound, G, K; };     // haplotypes up to `bound` bp: G pairs per wavefront, K positions per lane
 const HapClassDef kHapClasses[DD_N_HAP_CLASSES] = {
-    {30, 2, 1}, {62, 1, 1}, {94, 2, 3}, {126, 1, 2}, {158, 2, 5}, {190, 1, 3}, {222, 2, 7}, {254, 1, 4},
+    {30, 2, 1}, {62, 1, 1}, {94, 2, 3}, {126, 1, 2}, {158, 2, 5}, {190, 1, 3}, {222, 1, 4}, {254, 1, 4},
     {318, 1, 5}, {382, 1, 6}, {446, 1, 7}, {510, 1, 8}, {574, 1, 9}, {638, 1, 10}, {702, 1, 11}, {DD_MAX_HAP_LEN, 1, 12}};
 bool half_wave_off() { return getenv("DD_NO_HALF") != nullptr; }   // A/B and tests: whole-wavefront tilings only
 int hap_class_of(int hap_len)
@@ -71,9 +74,8 @@ bool pick_tiling(int max_hap_len, int Dt, int &G, int &K)
     const int c = hap_class_of(max_hap_len);
     if (c < 0) return false;
     G = kHapClasses[c].G; K = kHapClasses[c].K;
-    // K = 7 halves only on the D = 6 build: at D = 11 / 12 the sweep's register need halves its rate (1.26e11 against 2.09e11 cells/s on a
-    // whole wavefront at 200 bp, maxLengthDel 10; the other half tilings gain 9-16 % there too: profiles/r04/tiling_sweep_mld10.jsonl)
-    if (G > 1 && (half_wave_off() || (K == 7 && Dt > 7))) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
+    (void)Dt;                                       // (the half tilings in use gain at every D build: 9-16 % at maxLengthDel 10 / 11)
+    if (G > 1 && half_wave_off()) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
     return true;
 }
 
@@ -211,7 +213,8 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     // shape measured (+26 ... +41 % in round 2; +10 ... +30 % on the round-3 grid) — except K = 3 at D = 6 with reads short
     // enough (<= 90 bp) for the LDS tile to keep the 8 waves its registers allow: there the LDS build is 4-10 % ahead of the
     // scratch build (profiles/r03/plan_check.jsonl, k3_lds_vs_scratch.jsonl), so that case follows the K <= 2 rule.
-    const bool lean_only = pl.K >= 3 && !(pl.K == 3 && pl.Dt <= 7);
+    // Round 4 (profiles/r04/plan_check.jsonl): K = 4 at D = 6 with reads up to ~80 bp is 17-18 % faster on the LDS build too (at 100 bp it loses 20 %).
+    const bool lean_only = pl.K >= 3 && !(pl.K == 3 && pl.Dt <= 7) && !(pl.G == 1 && pl.K == 4 && pl.Dt <= 7 && max_read_len <= 80);
     pl.gbt = best[0] == 0 || (lean_only && best[1] > 0) || best[0] < cap[0];
     if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
         if (f[0] == '1' && best[1] > 0) pl.gbt = true;

@@ -97,7 +97,7 @@ __device__ __forceinline__ int xcd_contiguous_block_id(int n_items_in_launch)
  * DD_BUILD_TWO_WAVES: the K = 3 / D = 6 scratch build compiled for 2 waves per SIMD instead of 3 */
 #define DD_BUILD_FOLD 1
 #define DD_BUILD_TWO_WAVES 2
-#define DD_BUILD_HALF 4       /* two pairs per wavefront on 32-lane halves (K positions per lane of a half): K = 1, 3, 5, 7 */
+#define DD_BUILD_HALF 4       /* two pairs per wavefront on 32-lane halves (K positions per lane of a half): K = 1, 3, 5 */
 hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);
 hipError_t launch_onhap(const KernelArgs &A, hipStream_t st);
 hipError_t launch_faster(const KernelArgs &A, unsigned grid, int waves, size_t lds_bytes, hipStream_t st);   /* faster_kernel.hip */

@@ -201,7 +201,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // the CU anyway — there the 3-wave build's spills cost 9 % and buy nothing (profiles/r03/plan_check.jsonl).
 // G: pairs a wavefront works on at a time.  G = 2 (round 4): two reads of the haplotype side by side on the two 32-lane halves, K
 // positions per lane of a half, so a pair costs K / 2 lane-positions per read base instead of ceil((Hs + 2) / 64): haplotypes of
-// 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), 191..222 bp as K = 7 halves, <= 30 bp as K = 1 halves (capi.cpp kHapClasses).
+// 127..158 bp run as K = 5 halves (2.5 instead of 3), 63..94 bp as K = 3 halves (1.5 instead of 2), <= 30 bp as K = 1 halves (capi.cpp kHapClasses).
 // The two reads advance base by base together (their trip counts are padded to the longer one, the shorter one's lanes masked off), so
 // the workgroup first orders the window's reads by (length, bMid) and a wavefront takes two consecutive ranks.  Every
 // per-read quantity that the G = 1 build keeps on the scalar unit is a per-lane value here, equal across the lanes of a half.
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // ======================= loop over this wave's reads =======================
     // The haplotype's workgroups share its reads in contiguous blocks; inside a workgroup the wavefronts pull the next read from a counter
     // in LDS when they are free.  G = 2: the window's reads are taken in chunks of DD_HALF_CHUNK; every workgroup of the haplotype orders
-    // the chunk's reads of this launch's length class by (L, bMid) — the two pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) +
+    // the chunk's reads of this launch's length class by (length bucket, bMid) — the two pairs of a wavefront run max(L1-1-bMid1, L2-1-bMid2) +
     // max(bMid1, bMid2) sweeps, so they should agree in both — and a pull takes two consecutive ranks.  Results do not depend on the order.
     const int nChunks = (G == 1) ? 1 : (R + DD_HALF_CHUNK - 1) / DD_HALF_CHUNK;
     for (int chunk0 = 0, ci = 0; ci < nChunks; ci++, chunk0 += DD_HALF_CHUNK) {
@@ -524,7 +524,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             uint32_t key = 0xffffffffu;            // not of this launch's length class: behind every read that is
             if (L >= P.len_min && L <= P.len_max) {
                 if (!hap_ok) { if (split == 0) mark_hapsize(chunk0 + t, 0, 1); }
-                else key = ((uint32_t)((L - 1) & 2047) << 11) | (uint32_t)bmid_of(rr, L);   // length first: both trip counts follow it
+                else {
+                    // Pairs of consecutive ranks run max(nInc1, nInc2) + max(nDec1, nDec2) sweeps (nDec = bMid, nInc = L - 1 - bMid): order by
+                    // length in buckets of 8 bases, inside a bucket by bMid — ascending in even buckets, descending in odd ones, so that the
+                    // ranks either side of a bucket boundary are close in bMid too.  Reads of one length: plain bMid order.
+                    const uint32_t bucket = (uint32_t)(L - 1) >> 3, bm = (uint32_t)bmid_of(rr, L);
+                    key = (bucket << 11) | ((bucket & 1u) ? 1023u - bm : bm);
+                }
             }
             skey[t] = key;
         }
@@ -1323,7 +1329,7 @@ static hipError_t launch_k(int K, const KernelArgs &A, dim3 grid, int waves, siz
     }
 }
 
-// half-wave builds (two pairs per wavefront): K = 1, 3, 5, 7 positions per lane of a 32-lane half
+// half-wave builds (two pairs per wavefront): K = 1, 3, 5 positions per lane of a 32-lane half
 template <int D, bool GBT>
 static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, size_t lds, hipStream_t st)
 {
@@ -1331,7 +1337,6 @@ static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, 
     case 1: return launch_one<1, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 3: return launch_one<3, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
     case 5: return launch_one<5, D, GBT, false, 0, 2>(A, grid, waves, lds, st);
-    case 7: if constexpr (D == 6) return launch_one<7, D, GBT, false, 0, 2>(A, grid, waves, lds, st); else return hipErrorInvalidValue;   // (capi.cpp pick_tiling)
     default: return hipErrorInvalidValue;
     }
 }

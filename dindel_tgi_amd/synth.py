@@ -136,7 +136,8 @@ def concat(parts) -> PackedBatch:
     return PackedBatch(hap_var_flank=np.concatenate(flank), **{k: np.concatenate(v) for k, v in out.items()})
 
 
-def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_indel=12, fix_reads=0, fix_read_len=0, fix_haps=0, trimmed=True) -> PackedBatch:
+def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_indel=12, fix_reads=0, fix_read_len=0, fix_haps=0, trimmed=True, trimmed_every=5,
+                    extra_mean=9.0) -> PackedBatch:
     """Windows in the shapes the reference's own pipeline produces (fixed seed; bench.py's `ragged` leg, tests):
 
     * reference haplotype = [minRef - 60, maxRef + 60] around the window's candidates (python/makeWindows.py:72-75): 121 bp for a
@@ -151,7 +152,7 @@ def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_in
     rng = np.random.Generator(np.random.PCG64(seed))
     parts = []
     for i in range(n_windows):
-        extra = 0 if rng.random() < 0.45 else int(min(max_extra, rng.geometric(1.0 / 9.0)))
+        extra = 0 if rng.random() < 0.45 else int(min(max_extra, rng.geometric(1.0 / extra_mean)))
         H = int(rng.integers(2, 13))
         R = int(np.exp(rng.uniform(np.log(20.0), np.log(float(max_reads)))))
         L = int(rng.choice([36, 76, 100, 150], p=[0.1, 0.25, 0.45, 0.2]))
@@ -159,5 +160,5 @@ def generate_ragged(n_windows, seed=0x5EED4, max_reads=400, max_extra=40, max_in
         if fix_read_len: L = fix_read_len
         if fix_haps: H = fix_haps
         parts.append(generate(1, H=H, R=R, L=L, hap_len=121 + extra, seed=int(rng.integers(1, 2 ** 31)), max_indel=int(rng.integers(1, max_indel + 1)),
-                              vary_read_len=(trimmed and i % 5 == 4), mixed_quals=True))
+                              vary_read_len=(trimmed and i % trimmed_every == trimmed_every - 1), mixed_quals=True))
     return concat(parts)

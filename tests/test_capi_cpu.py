@@ -172,15 +172,15 @@ def test_launch_plan_rules(lib, monkeypatch):
         assert lib.dd_plan_info(C.byref(p), hap, L, 1, reads, haps, C.byref(out)) == 0, capi.last_error()
         return dict(K=out[0], D=out[1], hbm=out[2], waves=out[3], split=out[4], lds=out[5], scratch_kib=out[6], waves_cu=out[7], G=out[8])
     # lane tiling by haplotype length: numS = Hs+2 <= 64 K on a whole wavefront, or <= 32 K on a half (two pairs per wavefront, round 4)
-    # where that is the tighter fit and measured faster: <= 30, 63..94, 127..158, 191..222 bp
+    # where that is the tighter fit and measured faster: <= 30, 63..94, 127..158 bp
     hs = (30, 31, 62, 63, 94, 95, 126, 127, 158, 159, 190, 191, 222, 223, 254, 255, 318, 319, 382, 383, 446, 447, 510, 511, 702, 703, 766)
     assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in hs] == \
-        [(2, 1), (1, 1), (1, 1), (2, 3), (2, 3), (1, 2), (1, 2), (2, 5), (2, 5), (1, 3), (1, 3), (2, 7), (2, 7), (1, 4), (1, 4), (1, 5), (1, 5),
+        [(2, 1), (1, 1), (1, 1), (2, 3), (2, 3), (1, 2), (1, 2), (2, 5), (2, 5), (1, 3), (1, 3), (1, 4), (1, 4), (1, 4), (1, 4), (1, 5), (1, 5),
          (1, 6), (1, 6), (1, 7), (1, 7), (1, 8), (1, 8), (1, 9), (1, 11), (1, 12), (1, 12)]
     monkeypatch.setenv("DD_NO_HALF", "1")                      # A/B switch: whole-wavefront tilings only
     assert [(plan(hap=h)["G"], plan(hap=h)["K"]) for h in (30, 62, 63, 127, 191, 222)] == [(1, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 4)]
     monkeypatch.delenv("DD_NO_HALF")
-    assert [(plan(hap=h, mld=10)["G"], plan(hap=h, mld=10)["K"]) for h in (30, 94, 158, 222)] == [(2, 1), (2, 3), (2, 5), (1, 4)]   # K = 7 halves: D = 6 build only
+    assert [(plan(hap=h, mld=10)["G"], plan(hap=h, mld=10)["K"]) for h in (30, 94, 158, 222)] == [(2, 1), (2, 3), (2, 5), (1, 4)]   # the same tilings on the D = 11 build
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6
@@ -188,7 +188,9 @@ def test_launch_plan_rules(lib, monkeypatch):
     assert plan(hap=170)["hbm"] == 1 and plan(hap=170)["scratch_kib"] > 0 and plan()["scratch_kib"] == 0
     # K = 3 at D = 6: the LDS tile for reads up to 90 bp (it then holds the 8 waves the registers allow), scratch beyond and for maxLengthDel >= 6 / K >= 4
     assert [plan(hap=170, L=l)["hbm"] for l in (36, 76, 90, 100, 150)] == [0, 0, 0, 1, 1]
-    assert plan(hap=170, L=76, mld=10)["hbm"] == 1 and plan(hap=200, L=76)["hbm"] == 1
+    assert plan(hap=170, L=76, mld=10)["hbm"] == 1 and plan(hap=200, L=100)["hbm"] == 1
+    # K = 4 at D = 6 (191..254 bp): the LDS build for reads up to ~80 bp (17-18 % ahead there, profiles/r04/plan_check.jsonl), scratch beyond
+    assert [plan(hap=240, L=l)["hbm"] for l in (36, 76, 80, 81, 100)] == [0, 0, 0, 1, 1] and plan(hap=240, L=76, mld=10)["hbm"] == 1
     assert plan()["waves"] == 4 and plan()["waves_cu"] == 12 and plan()["lds"] <= 160 * 1024
     # workgroup size follows how well the windows' reads fill the waves
     assert [plan(reads=r)["waves"] for r in (1, 2, 3, 5, 10, 20, 200)] == [1, 2, 3, 1, 2, 4, 4]

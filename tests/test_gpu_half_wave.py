@@ -1,5 +1,5 @@
 """GPU parity of the half-wave builds (two reads of a haplotype side by side on the 32-lane halves of a wavefront, hmm_kernel.hip G = 2):
-bit-equal to the oracle and to the whole-wavefront builds (DD_NO_HALF=1), through the C ABI.  Covers every half tiling in use (K = 1, 3, 5, 7
+bit-equal to the oracle and to the whole-wavefront builds (DD_NO_HALF=1), through the C ABI.  Covers every half tiling in use (K = 1, 3, 5
 positions per lane), the three D builds, both back-pointer placements, windows with an odd number of reads (the second pair of the last
 wavefront is missing), reads of very different lengths and bMid in one window (padded trip counts), reads of another length class,
 haplotypes shorter than maxLengthDel, and more reads than one ordering chunk holds."""
@@ -14,7 +14,7 @@ from tests.test_gpu_edge_cases import reads_from, rnd
 
 pytestmark = pytest.mark.gpu
 RNG = np.random.default_rng(4242)
-HALF_K = {20: 1, 30: 1, 63: 3, 80: 3, 94: 3, 127: 5, 140: 5, 158: 5, 191: 7, 222: 7}
+HALF_K = {20: 1, 30: 1, 63: 3, 80: 3, 94: 3, 127: 5, 140: 5, 158: 5}
 
 
 def windows_for(hs, n_reads, lens=(36, 100)):
@@ -42,10 +42,6 @@ def test_half_wave_builds_equal_oracle_and_whole_wave_builds(lib, monkeypatch, h
         p.maxLengthDel = mld
         got = run_host_api(lib, p, pb)
         log = capi.launch_log()
-        if HALF_K[hs] == 7 and mld > 5:                                  # K = 7 halves: the D = 6 build only
-            assert all(r["pairs_per_wave"] == 1 for r in log), log
-            assert_same(got, _oracle.batch(p, pb, nthreads=8), pb)
-            continue
         assert any(r["pairs_per_wave"] == 2 and r["K"] == HALF_K[hs] for r in log), log
         want = _oracle.batch(p, pb, nthreads=8)
         assert_same(got, want, pb)
@@ -88,7 +84,7 @@ def test_half_wave_hapsize_error_and_empty_windows(lib):
 
 def test_half_wave_fuzz_with_variants_and_mates(lib):
     from tests.test_gpu_fuzz import make_windows
-    for seed, max_hap, mld in ((1, 94, 5), (2, 158, 5), (3, 158, 10), (4, 30, 3), (5, 222, 4)):
+    for seed, max_hap, mld in ((1, 94, 5), (2, 158, 5), (3, 158, 10), (4, 30, 3), (5, 150, 11)):
         rng = np.random.default_rng(7000 + seed)
         ws = make_windows(rng, 60, max_hap, 120, min_hap=max(mld, 1), with_vars=True)
         p = capi.params_cli_defaults()

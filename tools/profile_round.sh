@@ -13,14 +13,14 @@ cd /tmp
 export TMPDIR=/tmp
 python3 $R/bench.py --steps 5 --warmup 1 $BENCH_EXTRA "$@" > $OUT/bench.json      # BENCH_EXTRA=--host-api: un-profiled line only
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --kernel-only "$@" > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --kernel-only --no-ragged "$@" > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 echo "trace done"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-only "$@" > $OUT/pmc_$i.json 2> $OUT/pmc_$i.log
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-only --no-ragged "$@" > $OUT/pmc_$i.json 2> $OUT/pmc_$i.log
   echo "pmc pass $i done"
 done
 python3 $R/tools/pmc_summary.py $OUT "$KSUB" $OUT/bench.json > $OUT/pmc.json
