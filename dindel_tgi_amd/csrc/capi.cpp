@@ -74,8 +74,10 @@ bool pick_tiling(int max_hap_len, int Dt, int &G, int &K)
     const int c = hap_class_of(max_hap_len);
     if (c < 0) return false;
     G = kHapClasses[c].G; K = kHapClasses[c].K;
-    (void)Dt;                                       // (the half tilings in use gain at every D build: 9-16 % at maxLengthDel 10 / 11)
-    if (G > 1 && half_wave_off()) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
+    // (the half tilings in use gain at the D = 6, 11 and 12 builds: 9-16 % at maxLengthDel 10 / 11; the D = 32 build exists for whole
+    // wavefronts only, up to K = 9 — 574 bp — because a position's back-pointer takes 7 bits there)
+    if (G > 1 && (half_wave_off() || Dt > 12)) { G = 1; K = (kHapClasses[c].bound + 2 + 63) / 64; }
+    if (Dt > 12 && K > 9) return false;
     return true;
 }
 
@@ -85,7 +87,8 @@ int pick_Dt(int D)
     // (maxLengthDel 0..4 on the D=6 build: 2.4e11 -> 4.0e11 cells/s at configs[1]; 6..9 on the D=11 build)
     if (D <= 6) return 6;
     if (D <= 11) return 11;
-    return 12;
+    if (D <= 12) return 12;
+    return 32;                                    // maxLengthDel 12..31: the one build for the values beyond the reference's defaults (5 / 10)
 }
 
 uint32_t up16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -104,7 +107,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
     A.n_qual = n_qual;
     A.lds_off_C = o;  A.lds_off_Y = o;
     if ((gbt || G > 1) && (Dt > 7 || K >= 3)) {  // LEAN build: block-shared Inc constants + (y-1)*II (hmm_kernel.hip)
-        o += up16((uint32_t)K * Dt * W * 8u);
+        if (Dt <= 12) o += up16((uint32_t)K * Dt * W * 8u);   // (the D = 32 build forms these constants on the fly)
         A.lds_off_Y = o;  o += up16((uint32_t)Dt * 8u);
     }
     A.lds_off_W = o;  o += 16;                   // the workgroup's work counter
@@ -121,7 +124,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
     A.lds_group_bytes = wv;                      // the rows above exist once per pair of the wavefront; the back-pointer tile is the wavefront's
     wv *= (uint32_t)G;
     {   // packed back-pointers: one word of K*(CB+1) bits per lane per read base (BtPack in hmm_kernel.hip)
-        const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
+        const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : (Dt <= 15 ? 5u : 7u));
         const uint32_t bytes = bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
         A.lds_off_bt = wv;
         if (!gbt) wv += up16((uint32_t)Lmax * 64u * bytes);   // GBT builds keep the tile in HBM scratch
@@ -134,6 +137,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
 int reg_limited_waves_per_cu(int K, int Dt, bool gbt, int G = 1)
 {
     (void)G;
+    if (Dt > 12) return 4;                        // the D = 32 build: one wave per SIMD
     if (const char *e = getenv("DD_REG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) return v; }   // A/B builds with another occupancy
     if (K <= 2) return (Dt <= 7 || gbt) ? 12 : 8;
     if (K == 3) return (gbt && Dt <= 7) ? 12 : ((gbt || Dt <= 7) ? 8 : 4);      // round 3: the D = 6 scratch build is held to 168 VGPRs (3 waves/SIMD)
@@ -144,7 +148,7 @@ int reg_limited_waves_per_cu(int K, int Dt, bool gbt, int G = 1)
 
 uint32_t bt_word_bytes(int K, int Dt)
 {
-    const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : 5u);
+    const uint32_t bits = (uint32_t)K * ((Dt <= 7) ? 4u : (Dt <= 15 ? 5u : 7u));
     return bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
 }
 
@@ -173,7 +177,8 @@ struct Plan {
 int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual, Plan &pl, ddk::KernelArgs &A)
 {
     pl.Dt = pick_Dt(p->maxLengthDel + 1);
-    if (!pick_tiling(max_hap_len, pl.Dt, pl.G, pl.K)) return fail(DD_ERR_UNSUPPORTED, "haplotype too long");
+    if (!pick_tiling(max_hap_len, pl.Dt, pl.G, pl.K))
+        return fail(DD_ERR_UNSUPPORTED, pl.Dt > 12 ? "haplotype longer than 574 bp with maxLengthDel > 11" : "haplotype too long");
     int best[2] = {0, 0}, bw[2] = {0, 0}, cap[2] = {0, 0};
     for (int gbt = 0; gbt < 2; gbt++) {
         const int reg_cap = reg_limited_waves_per_cu(pl.K, pl.Dt, gbt != 0, pl.G);
@@ -187,6 +192,7 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
             if (total > best[gbt]) { best[gbt] = total; bw[gbt] = wv; }
         }
     }
+    if (pl.Dt > 12) best[0] = 0;                   // the D = 32 build keeps its back-pointers in the HBM scratch only
     if (best[0] == 0 && best[1] == 0)
         return fail(DD_ERR_UNSUPPORTED, "read length x haplotype length does not fit the LDS row buffers");
     // K = 3 / D = 6 scratch: the 3-waves-per-SIMD build only where LDS lets 12 waves stay (reads up to ~250 bp); beyond, the build
@@ -237,7 +243,7 @@ int check_params(const dd_params *p)
 {
     if (!p) return fail(DD_ERR_INVALID, "null params");
     if (p->forceReadOnHaplotype) return fail(DD_ERR_UNSUPPORTED, "forceReadOnHaplotype is not on the production path (DInDel.cpp:1446 only)");
-    if (p->maxLengthDel < 0 || p->maxLengthDel > DD_MAX_LENGTH_DEL) return fail(DD_ERR_UNSUPPORTED, "maxLengthDel outside [0,11]");
+    if (p->maxLengthDel < 0 || p->maxLengthDel > DD_MAX_LENGTH_DEL) return fail(DD_ERR_UNSUPPORTED, "maxLengthDel outside [0,31]");
     if (!(p->pError > 0.0 && p->pError < 1.0)) return fail(DD_ERR_INVALID, "pError outside (0,1)");
     return DD_SUCCESS;
 }

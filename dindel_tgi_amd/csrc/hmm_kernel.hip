@@ -156,7 +156,7 @@ __device__ __forceinline__ void slice_argmax(const double (&vA)[K], const double
 
 // Back-pointer packing: per position CB bits of transition choice (0 = from the inserted state, y = jump
 // length; LO/RO use their own small codes) + 1 bit for the inserted state's choice.  D <= 7 -> 4 bits per
-// position, else 5.  One lane's K positions of one slice go into one 1/2/4/8-byte word in LDS.
+// position, 5 up to D = 15, 7 on the D = 32 build (K <= 9 there: 63 bits).  One lane's K positions of one slice go into one 1/2/4/8-byte word.
 // a pair of a window that dd_screen_windows flagged: DD_PAIR_UNSUPPORTED, ll = 0, "off the haplotype"
 __device__ __forceinline__ void mark_unsupported(const dd_result &o, int64_t pair)
 {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void mark_unsupported(const dd_result &o, int64_t pai
 #define DD_LEAN_RULE(K, D, GBT, G) (((GBT) || (G) > 1) && ((D) > 7 || (K) >= 3))
 #endif
 template <int K, int D> struct BtPack {
-    static constexpr int CB = (D <= 7) ? 3 : 4;
+    static constexpr int CB = (D <= 7) ? 3 : (D <= 15 ? 4 : 6);       // D = 32 build (maxLengthDel 12..31): choices 0..32
     static constexpr int PB = CB + 1;
     static constexpr int BITS = K * PB;
     static constexpr int BYTES = BITS <= 8 ? 1 : BITS <= 16 ? 2 : BITS <= 32 ? 4 : 8;
@@ -188,7 +188,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // D = 6 scratch build at 3 waves/SIMD (168 VGPRs, a few spills outside the sweeps) gains 10-12 % (231.7 -> 207.2 ms per 3,000 windows of
 // 160-bp haplotypes); the D = 11 one loses 14 % to its spills and stays at 2, as does K = 4.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K, D, GBT, G) ((K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : ((((K) <= 5 || (G) == 2) && (GBT)) ? 2 : 1))
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT, G) ((D) > 12 ? 1 : (K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : ((((K) <= 5 || (G) == 2) && (GBT)) ? 2 : 1))
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     __syncthreads();
 
     if constexpr (LEAN) {
+        if constexpr (D <= 12)                     // (the D = 32 build forms these on the fly: its table would take 16 KB x K of LDS)
         for (int i = tid; i < K * D * W; i += nthr) {
             const int l = i & (W - 1), ky = i / W, k = ky / D, y = ky - k * D + 1;
             const int src = l * K + k + y;
@@ -641,7 +642,13 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
             }
             if (foldLO && lane == 63) { a[K - 1] = 0.0; in[K - 1] = 0.0; }      // beta[L-1][LO] = beta[L-1][numS] = 0, at LO's position in this pass
             auto cinc = [&](int k, int y) -> double {       // y = 1..D
-                if constexpr (LEAN) return shC[(k * D + y - 1) * W + lane]; else return cInc[k][y - 1];
+                if constexpr (LEAN && D > 12) {                 // D = 32 build: from the haplotype's tables, every read base (correct, not fast)
+                    const int src = x0 + k + y;
+                    if (src > RO || y > Dr) return NEG_INF;
+                    const double Es = shE[src], Ns = shN[src];
+                    const double lp = (y == 1) ? Ns : Es + (double)(y - 1) * II;
+                    return lp + Ns;
+                } else if constexpr (LEAN) return shC[(k * D + y - 1) * W + lane]; else return cInc[k][y - 1];
             };
             // G = 2: both pairs run the longer pair's trip count, the lanes of the pair that is done wait masked.  (One loop for both forms,
             // no lambda for the body: with the body in a lambda the K = 2 / D = 11 scratch build spilled 38 registers instead of 6.)
@@ -1347,6 +1354,7 @@ static hipError_t launch_half(int K, const KernelArgs &A, dim3 grid, int waves, 
 hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d11(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 hipError_t launch_hmm_d12(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
+hipError_t launch_hmm_d32(int K, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st);
 #if DD_INST_D == 0 || DD_INST_D == 6
 hipError_t launch_hmm_d6(int K, bool gbt, int build, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
@@ -1376,9 +1384,30 @@ hipError_t launch_hmm_d12(int K, bool gbt, int build, const KernelArgs &A, dim3 
 }
 #endif
 
+#if DD_INST_D == 0 || DD_INST_D == 32
+// maxLengthDel 12..31 (the reference takes any --maxLengthIndel, DInDel.cpp:4157): one D = 32 build per K = 1..9 (7 bits of back-pointer per
+// position: 63 bits), whole wavefronts, scratch back-pointers, register-lean form, one wave per SIMD — built to be correct, not fast.
+hipError_t launch_hmm_d32(int K, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
+{
+    switch (K) {
+    case 1: return launch_one<1, 32, true>(A, g, waves, lds, st);
+    case 2: return launch_one<2, 32, true>(A, g, waves, lds, st);
+    case 3: return launch_one<3, 32, true>(A, g, waves, lds, st);
+    case 4: return launch_one<4, 32, true>(A, g, waves, lds, st);
+    case 5: return launch_one<5, 32, true>(A, g, waves, lds, st);
+    case 6: return launch_one<6, 32, true>(A, g, waves, lds, st);
+    case 7: return launch_one<7, 32, true>(A, g, waves, lds, st);
+    case 8: return launch_one<8, 32, true>(A, g, waves, lds, st);
+    case 9: return launch_one<9, 32, true>(A, g, waves, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif
+
 #ifdef DD_INST_COMMON
 hipError_t launch_hmm(int K, int Dt, bool gbt, int build, const KernelArgs &A, unsigned grid, int waves, size_t lds, hipStream_t st)
 {
+    if (Dt == 32) return (gbt && !(build & (DD_BUILD_FOLD | DD_BUILD_HALF))) ? launch_hmm_d32(K, A, dim3(grid), waves, lds, st) : hipErrorInvalidValue;
     switch (Dt) {
     case 6: return launch_hmm_d6(K, gbt, build, A, dim3(grid), waves, lds, st);
     case 11: return launch_hmm_d11(K, gbt, build, A, dim3(grid), waves, lds, st);

@@ -73,7 +73,8 @@ extern "C" {
 /* kernel limits (screened per window on the host before launch: dd_screen_windows) */
 #define DD_MAX_HAP_LEN      766   /* numS = Hs+2 <= 64 lanes x 12 positions                         */
 #define DD_MAX_READ_LEN    1024
-#define DD_MAX_LENGTH_DEL    11   /* D = maxLengthDel+1 <= 12: choice fits 4 bits, 5*D match bits fit 64 */
+#define DD_MAX_LENGTH_DEL    31   /* D = maxLengthDel + 1 <= 32.  0..11 run the specialised D = 6 / 11 / 12 builds; 12..31 one D = 32 build (correct, not tuned;
+                                     haplotypes up to 574 bp there) */
 #define DD_MAX_QUAL_TABLE   256
 #define DD_HP_TABLE          64   /* homopolymer run lengths >= 52 are all capped at 0.99            */
 

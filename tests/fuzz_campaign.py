@@ -32,7 +32,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(50000 + seed)
     kind = int(rng.integers(0, 3))
     p = capi.params_cli_defaults() if rng.random() < 0.5 else capi.params_struct_defaults()
-    p.maxLengthDel = int(rng.integers(0, 12))
+    p.maxLengthDel = int(rng.integers(0, 12)) if rng.random() < 0.9 else int(rng.integers(12, 32))   # 12..31: the D = 32 build (haplotypes up to 574 bp)
     p.padCover = int(rng.integers(0, 6))
     p.maxMismatch = int(rng.integers(0, 4))
     p.pError = float(rng.choice([5e-4, 1e-4, 1e-2, 0.2]))
@@ -43,6 +43,8 @@ while time.time() < t_end:
         p.bMid = int(rng.integers(0, 30))
     if kind == 0:
         max_hap = int(rng.choice([23, 40, 62, 87, 126, 151, 190, 215, 254, 400, 755]))   # make_windows adds up to 7 inserted bases; every lane tiling incl. the half-wave ones
+        if p.maxLengthDel > 11 and max_hap > 560:
+            max_hap = 560
         ws = make_windows(rng, int(rng.integers(5, 60)), max_hap, int(rng.choice([30, 100, 160, 300, 700])), min_hap=1,
                           with_vars=bool(rng.random() < 0.6))
         libs = None

@@ -112,8 +112,8 @@ def test_no_cpu_fallback_and_validation(lib):
     assert "mapUnmappedReads" in capi.last_error()
     p4 = capi.params_cli_defaults(); p4.forceReadOnHaplotype = 1
     assert lib.dd_compute_likelihoods(C.byref(p4), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
-    p3 = capi.params_cli_defaults(); p3.maxLengthDel = 12
-    assert lib.dd_compute_likelihoods(C.byref(p3), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED
+    p3 = capi.params_cli_defaults(); p3.maxLengthDel = 32                   # 0..31 are supported (12..31 on the one D = 32 build)
+    assert lib.dd_compute_likelihoods(C.byref(p3), C.byref(b), C.byref(res), 0) == capi.DD_ERR_UNSUPPORTED and "[0,31]" in capi.last_error()
     res2 = capi.dd_result()
     assert lib.dd_compute_likelihoods(C.byref(p), C.byref(b), C.byref(res2), 0) == capi.DD_ERR_INVALID
 
@@ -183,6 +183,11 @@ def test_launch_plan_rules(lib, monkeypatch):
     assert [(plan(hap=h, mld=10)["G"], plan(hap=h, mld=10)["K"]) for h in (30, 94, 158, 222)] == [(2, 1), (2, 3), (2, 5), (1, 4)]   # the same tilings on the D = 11 build
     # D routing: a smaller D runs on the next larger specialised build
     assert [plan(mld=m)["D"] for m in range(12)] == [6] * 6 + [11] * 5 + [12]
+    # maxLengthDel 12..31 (the reference takes any --maxLengthIndel, DInDel.cpp:4157): one D = 32 build, whole wavefronts, scratch back-pointers, up to 574 bp
+    assert [(plan(mld=m, hap=h)["D"], plan(mld=m, hap=h)["G"], plan(mld=m, hap=h)["hbm"]) for m, h in ((12, 140), (20, 80), (31, 574))] == [(32, 1, 1)] * 3
+    out = (C.c_int32 * 10)()
+    p32 = capi.params_cli_defaults(); p32.maxLengthDel = 12
+    assert lib.dd_plan_info(C.byref(p32), 575, 100, 1, 200, 8, C.byref(out)) == capi.DD_ERR_UNSUPPORTED and "574" in capi.last_error()
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6
     assert [plan(L=l)["hbm"] for l in (36, 100, 110, 120, 150, 250, 1000)] == [0, 0, 0, 1, 1, 1, 1]
     assert plan(hap=170)["hbm"] == 1 and plan(hap=170)["scratch_kib"] > 0 and plan()["scratch_kib"] == 0

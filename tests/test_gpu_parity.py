@@ -111,6 +111,31 @@ def test_parity_generic_D(lib, mld):
     assert_same(run_host_api(lib, p, pb), _oracle.batch(p, pb, nthreads=8), pb)
 
 
+@pytest.mark.parametrize("mld", [12, 13, 15, 16, 21, 30, 31])
+def test_parity_long_deletions(lib, mld):
+    """maxLengthDel 12..31: the D = 32 build (7-bit back-pointer fields, jump constants formed on the fly) on every lane tiling it has
+    (K = 1..9), reads on both sides of long deletions, a haplotype shorter than maxLengthDel (hapSize error.)."""
+    from dindel_tgi_amd.batch import pack
+    from tests.test_gpu_edge_cases import reads_from, rnd
+    ws = []
+    for hs in (mld, 40, 70, 126, 150, 200, 260, 330, 400, 470, 574):
+        if hs < mld:
+            continue
+        hap = rnd(hs)
+        cut = hs // 2
+        dl = min(mld, max(1, hs - cut - 2))
+        haps = [hap, hap[:cut] + hap[cut + dl:], hap[:cut] + hap[cut + max(1, dl // 2):]] if hs > 2 * mld + 4 else [hap]
+        reads = reads_from(hap, 5, min(100, max(20, hs)), junk=0.1) + (reads_from(haps[1], 4, min(90, max(20, hs - dl))) if len(haps) > 1 else [])
+        ws.append(Window(1000, haps, reads))
+    ws.append(Window(1000, [rnd(max(1, mld - 1)), rnd(60 if mld <= 60 else mld + 5)], reads_from(rnd(80), 3, 50)))     # first haplotype: hapSize error.
+    pb = pack(ws)
+    p = capi.params_cli_defaults()
+    p.maxLengthDel = mld
+    got = run_host_api(lib, p, pb)
+    assert all(r["D"] == 32 and r["pairs_per_wave"] == 1 and r["gbt"] == 1 for r in capi.launch_log())
+    assert_same(got, _oracle.batch(p, pb, nthreads=8), pb)
+
+
 def test_device_pointer_path_matches_host_path(lib):
     import torch
     from dindel_tgi_amd.device import DeviceBatch
