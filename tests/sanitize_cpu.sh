@@ -23,4 +23,14 @@ g++ -O1 -g -std=c++11 -pthread -fsanitize=thread -I"$H" -o /tmp/dindel_gpu_tsan 
 python tools/n2_pipeline_bench.py --windows 600 --dir /tmp/tsan_sample --procs 4 > /dev/null 2>&1 || true      # writes the sample; its own driver run needs a GPU
 TSAN_OPTIONS="halt_on_error=1" /tmp/dindel_gpu_tsan --bamFile /tmp/tsan_sample/reads.bam --varFile /tmp/tsan_sample/windows.txt \
     --hapFile /tmp/tsan_sample/haps.txt --outputFile /tmp/tsan_sample/o --prepareOnly --quiet --batchWindows 32 --prepareThreads 4
+# the same build over two BAM pools with injected late skips: the writer's re-preparation (own handles, own read buffer) beside the prepare workers
+python - <<'PY'
+import sys, pathlib
+sys.path.insert(0, ".")
+from tests.test_n2_pools_cpu import _scene
+p = pathlib.Path("/tmp/tsan_pools"); p.mkdir(exist_ok=True)
+_scene(p, n_ref=40000, n_reads=8000)
+PY
+TSAN_OPTIONS="halt_on_error=1" /tmp/dindel_gpu_tsan --bamFiles /tmp/tsan_pools/bams.txt --varFile /tmp/tsan_pools/windows.txt --hapFile /tmp/tsan_pools/haps.txt \
+    --outputFile /tmp/tsan_pools/o --prepareOnly --quiet --batchWindows 3 --prepareThreads 4 --injectLateSkip 4,9,10,20 2> /dev/null
 echo "thread sanitizer: clean"
