@@ -399,14 +399,24 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         for (int k = 0; k < K; k++) {
             const int x = xb + k;
             const bool valid = x < numS;
-            lpn[k] = valid ? shN[x] : NEG_INF;      // Dec: logProbNoError[x]
-            eIn[k] = valid ? shE[x] : NEG_INF;      // Dec: logProbError[x]   (insertion-open into x)
+            // Loaded for every lane, then selected (x < NP lies inside the tables): NO branch over part of the wavefront here.  hipcc (ROCm 7.2)
+            // put register-allocator spills of values that live across such a branch IN FRONT of the exec restore of its join block in three
+            // builds (K = 11 / D = 6 and K = 7 / D = 12 scratch, K = 7 / D = 12 LDS): the lanes that sat the branch out lost the LDS address of
+            // their constants from a workgroup's second item on (tools/check_exec_spills.py, tests/test_gpu_persistent_rounds.py).
+            double tn = shN[x], te = shE[x];
+            asm volatile("" : "+v"(tn), "+v"(te));  // (opaque: the loads are not sunk back under the condition)
+            lpn[k] = valid ? tn : NEG_INF;          // Dec: logProbNoError[x]
+            eIn[k] = valid ? te : NEG_INF;          // Dec: logProbError[x]   (insertion-open into x)
             niDec[k] = (x == 0) ? NEG_INF : NI;     // Dec: no "inserted -> on base" edge into LO (:1823 starts at x=1)
         }
     };
     auto load_inc_constants = [&](int xb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < K; k++) eInc[k] = (xb + k + 1 <= RO) ? shE[xb + k + 1] : NEG_INF;   // Inc: logProbError[x+1]
+        for (int k = 0; k < K; k++) {                // Inc: logProbError[x+1]   (x + 1 <= NP lies inside the table)
+            double te = shE[xb + k + 1];
+            asm volatile("" : "+v"(te));
+            eInc[k] = (xb + k + 1 <= RO) ? te : NEG_INF;
+        }
     };
     if constexpr (!SLIM) { load_dec_constants(x0); load_inc_constants(x0); }
 #pragma unroll
@@ -414,7 +424,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         const int x = x0 + k;
         const bool valid = x < numS;
         // bit c set <=> code_match(state symbol, c): 'N' / LO / RO match every column, another symbol its own, a pad none
-        const unsigned scode = sc[x];
+        unsigned scode = sc[x];
+        asm volatile("" : "+v"(scode));             // (as above: every lane loads, no branch)
         mOwn[k] = !valid ? 0u : (scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u));
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
