@@ -250,6 +250,8 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
     // to the slice window at 3 waves/SIMD; the Inc constants come from a block-shared LDS table instead (LDS is idle in
     // this build) and the Dec jump penalties are formed on the fly from E[x] and a broadcast (y-1)*II.
     constexpr bool LEAN = DD_LEAN_RULE(K, D, GBT, G);
+    constexpr bool BIGD = D > 12;                   // the D = 32 build (maxLengthDel 12..31): jump candidates in a run-time loop over y
+    static_assert(!BIGD || LEAN, "the D = 32 build is a scratch build (its Dec penalties come from shY)");
     // SLIM (K >= 3 or two pairs per wavefront): the builds that sit at their register budget keep less alive across the sweeps —
     // the per-position constants of a pass are (re)loaded from the haplotype's LDS tables right in front of that pass instead of once
     // per haplotype (their loads cannot be hoisted: the index goes through an opaque register), beta[bMid] waits in a wave-private LDS
@@ -424,9 +426,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
         const int x = x0 + k;
         const bool valid = x < numS;
         // bit c set <=> code_match(state symbol, c): 'N' / LO / RO match every column, another symbol its own, a pad none
-        unsigned scode = sc[x];
-        asm volatile("" : "+v"(scode));             // (as above: every lane loads, no branch)
-        mOwn[k] = !valid ? 0u : (scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u));
+        const unsigned scode = sc[x];
+        unsigned m = scode == DD_SYM_N ? 0xffffffffu : (scode < 32u ? 1u << scode : 0u);
+        asm volatile("" : "+v"(m));                 // (as above: every lane loads and forms its mask, a select drops it: no branch)
+        mOwn[k] = valid ? m : 0u;
     }
     const double Nn_RO = shN[RO], E_RO = shE[RO], E_Hs = shE[Hs], E_1 = shE[1];
     // Right->middle pass: the two end states ride in the generic candidate code instead of running as one-lane blocks of their
@@ -667,7 +670,10 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 if (G == 1 || it < nInc) {
                 const double eq = rdE[2 * b], uq = rdE[2 * b + 1];
                 const int col = rdC[b];
-                double v[D + K], ov[D + K];
+                // (D = 32 build: only the lane's own positions and the one behind them are staged; the jump candidates read their source from
+                // the LDS slice inside a run-time loop — 2 x (D + K) doubles per lane was 700-1,100 spilled registers per kernel)
+                constexpr int NVI = BIGD ? K + 1 : D + K;
+                double v[NVI], ov[NVI];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     const unsigned mk = (foldLO && k == K - 1) ? mLast : mOwn[k];
@@ -683,24 +689,55 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int j = 0; j < D; j++) {                      // states x0+K .. x0+K+D-1
+                for (int j = 0; j < NVI - K; j++) {                // states x0+K .. x0+K+D-1
                     const double2 t = rowA[((K + j) % K) * AQ + PADQ + lane + (K + j) / K];   // state x0+K+j
                     v[K + j] = t.x;
                     ov[K + j] = t.y;
                 }
                 double na[K], ni[K];
                 btacc_t btb[K];
+                double bestY[BIGD ? K : 1];
+                btacc_t chY[BIGD ? K : 1];
+                if constexpr (BIGD) {
+                    // the jump candidates y = 1..Dr of every position, y in a run-time loop (same order per position as the unrolled form:
+                    // y ascending, "take iff > best + EPS"; candidates beyond the real D are not formed instead of being -inf)
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        bestY[k] = (cinc(k, 1) + v[k + 1]) + ov[k + 1];
+                        chY[k] = (btacc_t)1;
+                    }
+#pragma unroll 1
+                    for (int y = 2; y <= Dr; y++) {
+                        const double yII = (double)(y - 1) * II;
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const int j = k + y, src = x0 + j;
+                            const double2 t = rowA[(j % K) * AQ + PADQ + lane + j / K];       // state x0+k+y
+                            double c = NEG_INF;
+                            if (src <= RO) { const double Ns = shN[src]; c = (shE[src] + yII) + Ns; }
+                            const double val = (c + t.x) + t.y;
+                            const bool take = val > bestY[k] + DD_EPS;
+                            bestY[k] = take ? val : bestY[k];
+                            chY[k] = take ? (btacc_t)y : chY[k];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    double best = (cinc(k, 1) + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
+                    double best;
                     const int sh = (D <= 7) ? k * BP::PB : 0;
-                    btacc_t ch = (btacc_t)1 << sh;
+                    btacc_t ch;
+                    if constexpr (BIGD) { best = bestY[k]; ch = chY[k]; }
+                    else {
+                    best = (cinc(k, 1) + v[k + 1]) + ov[k + 1];   // lp+lpn+beta+obs (:1735), y = 1
+                    ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
                         const double val = (cinc(k, y) + v[k + y]) + ov[k + y];
                         const bool take = val > best + DD_EPS;     // newIdx > destIdx: branch 1 only
                         best = take ? val : best;
                         ch = take ? ((btacc_t)y << sh) : ch;
+                    }
                     }
                     {
                         const double val = (eq + in[k]) + eInc[k]; // to inserted state numS+x (:1746-1749)
@@ -809,20 +846,23 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 if (G == 1 || b <= nDec) {
                 const double eq = rdE[2 * (b - 1)], uq = rdE[2 * (b - 1) + 1];
                 const int col = rdC[b - 1];
-                double v[D + K], ov[D + K];
+                // (DW = how many states below the lane's own are staged: D, or — D = 32 build — the one state the y = 1 edge and RO's block need;
+                // the array index of "state x0 + k - y" is DW + k - y)
+                constexpr int DW = BIGD ? 1 : D;
+                double v[DW + K], ov[DW + K];
                 // publish slice b-1 (value + this state's emission for read base b-1) for the neighbours
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    ov[D + k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
-                    v[D + k] = a[k];
-                    rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[D + k]);
+                    ov[DW + k] = ((mOwn[k] >> col) & 1u) ? eq : uq;
+                    v[DW + k] = a[k];
+                    rowA[k * AQ + PADQ + lane] = make_double2(a[k], ov[DW + k]);
                     rowI[1 + x0 + k] = in[k];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int j = 0; j < D; j++) {                      // states x0-D .. x0-1
-                    const int off = j - D, kk = ((off % K) + K) % K, q = (off - kk) / K;      // state x0-D+j = (lane+q)*K + kk
+                for (int j = 0; j < DW; j++) {                     // states x0-DW .. x0-1
+                    const int off = j - DW, kk = ((off % K) + K) % K, q = (off - kk) / K;     // state x0-DW+j = (lane+q)*K + kk
                     const double2 t = rowA[kk * AQ + PADQ + lane + q];
                     v[j] = t.x;
                     ov[j] = t.y;
@@ -830,20 +870,49 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                 const double im1 = rowI[x0];                        // I[x0-1]
                 double na[K], ni[K];
                 btacc_t btb[K];
+                double bestY[BIGD ? K : 1];
+                btacc_t chY[BIGD ? K : 1];
+                if constexpr (BIGD) {
+                    // jump candidates in a run-time loop over y (see the right->middle pass): source state x0 + k - y from the LDS slice
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        bestY[k] = ((ov[DW + k - 1] + lpn[k]) + v[DW + k - 1]) + lpn[k];
+                        chY[k] = (btacc_t)1;
+                    }
+#pragma unroll 1
+                    for (int y = 2; y <= Dr; y++) {
+                        const double yII = shY[y - 1];              // (y-1)*II
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const int jj = k - y + K * PADQ;        // >= 0: y <= D <= K * PADQ
+                            const double2 t = rowA[(jj % K) * AQ + lane + jj / K];            // state x0+k-y (pads hold -inf below state 0)
+                            const double lp = eIn[k] + yII;
+                            const double val = ((t.y + lp) + t.x) + lpn[k];
+                            const bool take = val >= bestY[k];
+                            bestY[k] = dmax(bestY[k], val);
+                            chY[k] = take ? (btacc_t)y : chY[k];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    double best = ((ov[D + k - 1] + lpn[k]) + v[D + k - 1]) + lpn[k];         // (:1793), y = 1: lp = lpn
+                    double best;
                     const int sh = (D <= 7) ? k * BP::PB : 0;     // field of this position in the packed word (D<=7: codes are
                                                                   // pre-shifted; larger codes would stop being inline constants)
-                    btacc_t ch = (btacc_t)1 << sh;
+                    btacc_t ch;
+                    if constexpr (BIGD) { best = bestY[k]; ch = chY[k]; }
+                    else {
+                    best = ((ov[DW + k - 1] + lpn[k]) + v[DW + k - 1]) + lpn[k];         // (:1793), y = 1: lp = lpn
+                    ch = (btacc_t)1 << sh;
 #pragma unroll
                     for (int y = 2; y <= D; y++) {
                         double lp;
                         if constexpr (LEAN) lp = eIn[k] + shY[y - 1]; else lp = lpDec[k][y - 1];
-                        const double val = ((ov[D + k - y] + lp) + v[D + k - y]) + lpn[k];
+                        const double val = ((ov[DW + k - y] + lp) + v[DW + k - y]) + lpn[k];
                         const bool take = val >= best;             // newIdx < destIdx: either branch of updateMax
                         best = dmax(best, val);
                         ch = take ? ((btacc_t)y << sh) : ch;
+                    }
                     }
                     {
                         const double ip = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
@@ -854,7 +923,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
                     }
                     na[k] = best;
                     const double d = (eq + in[k]) + II;            // stay inserted (:1816-1820)
-                    const double val = (ov[D + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
+                    const double val = (ov[DW + k] + a[k]) + niDec[k];   // open insertion after x (:1823-1826)
                     const bool take = val >= d;
                     ni[k] = dmax(d, val);
                     btb[k] = ch | (take ? ((btacc_t)(1u << BP::CB) << sh) : (btacc_t)0);
@@ -867,7 +936,7 @@ __global__ void __launch_bounds__(DD_WAVES * 64, OCC ? OCC : DD_MIN_WAVES_PER_SI
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         if (k == kRO) {
-                            const double aHs = v[D + k - 1], oHs = ov[D + k - 1];
+                            const double aHs = v[DW + k - 1], oHs = ov[DW + k - 1];
                             const double iHs = (k == 0) ? im1 : in[k > 0 ? k - 1 : 0];
                             // candidate order and indices: RO, Hs (< RO), numS+RO (largest), numS+Hs
                             double best = ((eq + a[k]) + lLL) + NN;

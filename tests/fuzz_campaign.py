@@ -22,6 +22,7 @@ from tests.test_gpu_faster import assert_same_faster, run_faster
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300)
 ap.add_argument("--seed0", type=int, default=0)
+ap.add_argument("--long-deletions", action="store_true", help="every round draws maxLengthDel from 12..31 (the D = 32 build) instead of one in ten")
 args = ap.parse_args()
 lib = capi.load()
 t_end = time.time() + args.seconds
@@ -33,6 +34,8 @@ while time.time() < t_end:
     kind = int(rng.integers(0, 3))
     p = capi.params_cli_defaults() if rng.random() < 0.5 else capi.params_struct_defaults()
     p.maxLengthDel = int(rng.integers(0, 12)) if rng.random() < 0.9 else int(rng.integers(12, 32))   # 12..31: the D = 32 build (haplotypes up to 574 bp)
+    if args.long_deletions:
+        p.maxLengthDel = int(rng.integers(12, 32))
     p.padCover = int(rng.integers(0, 6))
     p.maxMismatch = int(rng.integers(0, 4))
     p.pError = float(rng.choice([5e-4, 1e-4, 1e-2, 0.2]))

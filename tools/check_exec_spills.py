@@ -123,11 +123,49 @@ def check(body):
     return found
 
 
+def check_regions(body):
+    """The same fault without a label in between: `s_and_saveexec_b64 sN, ...` ... straight-line code ... `s_or_b64 exec, exec, sN`, and inside it a
+    spill store of a VGPR that the region itself did not write (dd_hmm_kernel<8, 6, GBT>: `v_accvgpr_write_b32 a3, v58` two instructions in front of
+    the restore; v58 is reloaded from a3 at the item loop's back edge)."""
+    found = []
+    open_at, saved, written, stores = None, None, set(), []
+    for l in body:
+        s = l.split(";")[0].strip()
+        if not s or (s.startswith(".") and not s.startswith(".LBB")):
+            continue
+        if s.startswith(".LBB"):
+            open_at = None                                 # a label: not straight-line any more (the join-head rule covers that form)
+            continue
+        parts = s.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        a = args.replace(" ", "")
+        if op == "s_and_saveexec_b64":
+            open_at, saved, written, stores = s, a.split(",")[0], set(), []
+            continue
+        if open_at is None:
+            continue
+        if op == "s_or_b64" and a.startswith("exec,exec,"):
+            if a.split(",")[2] == saved and stores:
+                found.append((open_at, stores, s))
+            open_at = None
+            continue
+        if op.startswith(("s_cbranch", "s_branch", "s_barrier", "s_endpgm")) or "exec" in a.split(",")[0]:
+            open_at = None
+            continue
+        if op == "v_accvgpr_write_b32" or op.startswith("scratch_store"):
+            if not (vregs(args.split(",")[1]) <= written):
+                stores.append(s)
+            continue
+        if op.startswith(("v_", "ds_read", "global_load", "scratch_load", "buffer_load")) and not op.startswith(("v_cmp", "v_writelane", "v_readlane", "v_readfirstlane")):
+            written |= vregs(args.split(",")[0])
+    return found
+
+
 def main():
     bad = 0
     for path in sys.argv[1:]:
         for name, body in kernels(path):
-            f = check(body)
+            f = check(body) + check_regions(body)
             if f:
                 bad += 1
                 print("%s: %s: %d block(s) with spill code in front of the exec restore" % (path.split("/")[-1], name, len(f)))
