@@ -220,7 +220,10 @@ int make_plan(const dd_params *p, int max_hap_len, int max_read_len, int n_qual,
     // enough (<= 90 bp) for the LDS tile to keep the 8 waves its registers allow: there the LDS build is 4-10 % ahead of the
     // scratch build (profiles/r03/plan_check.jsonl, k3_lds_vs_scratch.jsonl), so that case follows the K <= 2 rule.
     // Round 4 (profiles/r04/plan_check.jsonl): K = 4 at D = 6 with reads up to ~80 bp is 17-18 % faster on the LDS build too (at 100 bp it loses 20 %).
-    const bool lean_only = pl.K >= 3 && !(pl.K == 3 && pl.Dt <= 7) && !(pl.G == 1 && pl.K == 4 && pl.Dt <= 7 && max_read_len <= 80);
+    // End of round 4 (profiles/r04/plan_check.jsonl): with the item counter on every multi-round launch the scratch builds gained 10-18 % and the LDS builds
+    // 1 %, and the exceptions above lost: K = 4 / D = 6 with reads <= 80 bp ran 35-45 % BEHIND on the LDS build, K = 3 / D = 6 with short reads 4-12 %, and
+    // K = 2 on the D = 11 build 5-8 % at every read length the LDS tile fits.  Now: scratch for every K >= 3 and for K = 2 above D = 7.
+    const bool lean_only = pl.K >= 3 || (pl.K == 2 && pl.Dt > 7);
     pl.gbt = best[0] == 0 || (lean_only && best[1] > 0) || best[0] < cap[0];
     if (const char *f = getenv("DD_FORCE_GBT")) {                  // A/B only
         if (f[0] == '1' && best[1] > 0) pl.gbt = true;
@@ -1120,13 +1123,16 @@ static int launch_range(Model model, const dd_params *p, const dd_device_batch *
         const int64_t cap = (int64_t)pl.grid_cap * pl.waves / waves;
         if (grid > cap) grid = cap;
     }
-    // Ragged launch (reads per window or read lengths spread widely): a persistent grid that draws its items from a counter
+    // More items than the chip holds workgroups: a persistent grid that draws its items from a counter.  Built for the ragged launches (items that
+    // differ 20-fold in work); at the end of round 4 it turned out to be worth as much on UNIFORM batches wherever the grid was persistent
+    // already — every HBM-scratch build ran a fixed stride, and the items of a uniform batch still differ by their reads' bMid: 3.42 -> 3.85e11 cells/s
+    // at 130 bp, 3.34 -> 3.88e11 at 80 bp, +10-18 % on every K >= 3 tiling (profiles/r04/item_counter_uniform_ab.txt) — and +0.1-1.5 % on the
+    // one-shot LDS grids (the headline build: +0.9 %), whose XCD-contiguous numbering (one L2 per window's haplotypes) it gives up.
     hipStream_t st = static_cast<hipStream_t>(stream);
     A.work_counter = nullptr;
     {
-        const bool spread = A.reads_per_wave > 0 || (lc && lc->avg_read_len > 0 && lc->max_read_len * 4 > lc->avg_read_len * 5);
-        const char *e = getenv("DD_DYNAMIC");                                 // A/B: 0 = never, 1 = always
-        const bool dynamic = e ? (e[0] == '1') : spread;
+        const char *e = getenv("DD_DYNAMIC");                                 // A/B: 0 = never (one-shot LDS grids, fixed stride on scratch builds)
+        const bool dynamic = e ? (e[0] == '1') : true;
         if (dynamic && workspace && workspace_bytes >= DD_WS_HEADER && resident > 0 && n_launch_items > resident) {
             A.work_counter = static_cast<int32_t *>(workspace);
             HIP_TRY(hipMemsetAsync(workspace, 0, 4, st));

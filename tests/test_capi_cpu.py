@@ -191,11 +191,12 @@ def test_launch_plan_rules(lib, monkeypatch):
     # LDS tile while it costs no resident wave, HBM scratch beyond (K=2: reads up to ~115 bp), and always for K >= 4 / K = 3 at D > 6
     assert [plan(L=l)["hbm"] for l in (36, 100, 110, 120, 150, 250, 1000)] == [0, 0, 0, 1, 1, 1, 1]
     assert plan(hap=170)["hbm"] == 1 and plan(hap=170)["scratch_kib"] > 0 and plan()["scratch_kib"] == 0
-    # K = 3 at D = 6: the LDS tile for reads up to 90 bp (it then holds the 8 waves the registers allow), scratch beyond and for maxLengthDel >= 6 / K >= 4
-    assert [plan(hap=170, L=l)["hbm"] for l in (36, 76, 90, 100, 150)] == [0, 0, 0, 1, 1]
+    # end of round 4 (the item counter made the scratch builds 10-18 % faster): scratch for every K >= 3 whatever the read length, and for K = 2
+    # above D = 7 (profiles/r04/plan_check.jsonl; before: K = 3 / D = 6 on the LDS tile up to 90-bp reads, K = 4 / D = 6 up to 80 bp, K = 2 / D = 11 up to ~100)
+    assert [plan(hap=170, L=l)["hbm"] for l in (36, 76, 90, 100, 150)] == [1] * 5
     assert plan(hap=170, L=76, mld=10)["hbm"] == 1 and plan(hap=200, L=100)["hbm"] == 1
-    # K = 4 at D = 6 (191..254 bp): the LDS build for reads up to ~80 bp (17-18 % ahead there, profiles/r04/plan_check.jsonl), scratch beyond
-    assert [plan(hap=240, L=l)["hbm"] for l in (36, 76, 80, 81, 100)] == [0, 0, 0, 1, 1] and plan(hap=240, L=76, mld=10)["hbm"] == 1
+    assert [plan(hap=240, L=l)["hbm"] for l in (36, 76, 80, 81, 100)] == [1] * 5 and plan(hap=240, L=76, mld=10)["hbm"] == 1
+    assert [plan(mld=10, L=l)["hbm"] for l in (36, 76, 100)] == [1] * 3 and plan(mld=10, hap=43, L=76)["hbm"] == 0      # (K = 1 keeps the LDS rule)
     assert plan()["waves"] == 4 and plan()["waves_cu"] == 12 and plan()["lds"] <= 160 * 1024
     # workgroup size follows how well the windows' reads fill the waves
     assert [plan(reads=r)["waves"] for r in (1, 2, 3, 5, 10, 20, 200)] == [1, 2, 3, 1, 2, 4, 4]
