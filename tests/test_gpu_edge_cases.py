@@ -516,13 +516,19 @@ def test_multi_device_block_of_windows_without_haplotypes(lib):
     assert none["onHap"][:pe.n_reads].max() == 0
 
 
-def test_k3_scratch_build_variants(lib):
-    """K = 3 at D = 6: reads up to 90 bp run the LDS build, longer ones the scratch build compiled for 3 waves per SIMD, and reads so long
-    that LDS keeps fewer than 12 waves on the CU (> ~250 bp) its 2-waves-per-SIMD variant — all three equal the oracle."""
+def test_k3_scratch_build_variants(lib, monkeypatch):
+    """K = 3 at D = 6: the scratch build compiled for 3 waves per SIMD (since the end of round 4 for every read length: the item counter made it the
+    faster one below 90 bp too), for reads so long that LDS keeps fewer than 12 waves on the CU (> ~250 bp) its 2-waves-per-SIMD variant, and —
+    DD_FORCE_GBT=0 — the LDS build that short reads ran on before: all equal the oracle."""
     p = capi.params_cli_defaults()
     hap = rnd(175)                                                    # 159..190 bp: three positions per lane of a whole wavefront
     alt = hap[:70] + hap[73:]
-    for L, want_name in ((76, "dd_hmm_kernel<3, 6, false, false, 0, 1>"), (160, "dd_hmm_kernel<3, 6, true, false, 0, 1>"), (330, "dd_hmm_kernel<3, 6, true, false, 2, 1>")):
+    for L, force, want_name in ((76, None, "dd_hmm_kernel<3, 6, true, false, 0, 1>"), (76, "0", "dd_hmm_kernel<3, 6, false, false, 0, 1>"),
+                                (160, None, "dd_hmm_kernel<3, 6, true, false, 0, 1>"), (330, None, "dd_hmm_kernel<3, 6, true, false, 2, 1>")):
+        if force is None:
+            monkeypatch.delenv("DD_FORCE_GBT", raising=False)
+        else:
+            monkeypatch.setenv("DD_FORCE_GBT", force)
         pb = pack([Window(1000, [hap, alt], reads_from(hap, 14, L, junk=0.1) + reads_from(alt, 6, L, junk=0.0))])
         got = run_host_api(lib, p, pb)
         assert lib.dd_kernel_name().decode() == want_name, (L, lib.dd_kernel_name().decode())
@@ -557,17 +563,22 @@ def test_folded_end_states_equal_the_one_lane_blocks(lib, hs, monkeypatch):
     fits = G == 1 and 64 * K >= longest + 3                      # (the half-wave builds keep the one-lane blocks)
     assert name_plain.endswith("false, 0, %d>" % G) and name_folded.endswith(("true, 0, %d>" if fits else "false, 0, %d>") % G), (name_folded, name_plain)
     if K == 2:
-        # the two other builds that carry the fold: maxLengthDel = 10 (D build 11, LDS back-pointers) and reads long enough for the
-        # scratch build at D = 6
+        # the two other builds that carry the fold: maxLengthDel = 10 on the LDS build of D = 11 (since the end of round 4 only under DD_FORCE_GBT=0: the
+        # plan takes the scratch build there, which has no folded variant) and reads long enough for the scratch build at D = 6
         p10 = capi.params_cli_defaults(); p10.maxLengthDel = 10
         pl = pack([Window(1000, [hap, alt], reads_from(hap, 14, 170, junk=0.1) + reads_from(hap, 4, 200, junk=0.0))])
-        for params, batch, tag in ((p10, pb, "11, false"), (p, pl, "6, true")):
+        for params, batch, tag, force, folds in ((p10, pb, "11, true", None, False), (p10, pb, "11, false", "0", fits), (p, pl, "6, true", None, fits)):
+            if force is None:
+                monkeypatch.delenv("DD_FORCE_GBT", raising=False)
+            else:
+                monkeypatch.setenv("DD_FORCE_GBT", force)
             got = run_host_api(lib, params, batch)
             name = lib.dd_kernel_name().decode()
             monkeypatch.setenv("DD_NO_FOLD", "1")
             ref = run_host_api(lib, params, batch)
             monkeypatch.delenv("DD_NO_FOLD")
+            monkeypatch.delenv("DD_FORCE_GBT", raising=False)
             w2 = _oracle.batch(params, batch, nthreads=8)
             assert_same(got, w2, batch)
             assert_same(ref, w2, batch)
-            assert ("<2, %s, " % tag) in name and name.endswith("true, 0, 1>" if fits else "false, 0, 1>"), name
+            assert ("<2, %s, " % tag) in name and name.endswith("true, 0, 1>" if folds else "false, 0, 1>"), name
