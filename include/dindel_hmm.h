@@ -302,7 +302,9 @@ typedef struct dd_device_batch {   /* all DEVICE pointers; same meaning as dd_ba
                                                within the limits (max_hap_len / max_read_len then cover the whole batch) */
 } dd_device_batch;
 
-/* bytes of device scratch dd_launch_device needs for this shape (0 if none) */
+/* bytes of device scratch dd_launch_device needs for this shape: the back-pointer tiles of the HBM-scratch builds behind a 256-byte header whose
+ * first word is the item counter a launch zeroes (hipMemsetAsync on `stream`) and its workgroups draw from — never 0, and never shared by two
+ * launches that may run at the same time (one workspace per stream) */
 size_t dd_workspace_bytes(const dd_params *p, const dd_device_batch *b);
 
 /* Enqueue the whole path for the batch on `stream` (a hipStream_t, may be NULL = default stream).
