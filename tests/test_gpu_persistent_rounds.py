@@ -37,8 +37,8 @@ def clean_env():
             os.environ[k] = saved[k]
 
 
-@pytest.mark.parametrize("mld", [5, 10, 11, 15])
-def test_later_items_of_a_workgroup(lib, clean_env, mld):
+@pytest.mark.parametrize("mld,L", [(5, 100), (10, 100), (11, 100), (15, 100), (5, 36), (5, 194), (10, 194), (11, 36)])
+def test_later_items_of_a_workgroup(lib, clean_env, mld, L):
     persistent_multi_round = 0
     for c, bound in enumerate(capi.HAP_CLASS_BOUNDS):
         if mld > 11 and bound > 574:                     # the D = 32 build stops at K = 9
@@ -47,7 +47,7 @@ def test_later_items_of_a_workgroup(lib, clean_env, mld):
             continue
         p = capi.params_cli_defaults()
         p.maxLengthDel = mld
-        pb = synth.generate(14, H=8, R=48, L=100, hap_len=bound - 4, seed=77 + c, max_indel=3, sub_rate=0.01, mixed_quals=True)
+        pb = synth.generate(14, H=8, R=48, L=L, hap_len=bound - 4, seed=77 + c, max_indel=3, sub_rate=0.01, mixed_quals=True)
         want = _oracle.batch(p, pb, nthreads=16)
         for env in MODES:
             for k in KEYS:
@@ -60,7 +60,7 @@ def test_later_items_of_a_workgroup(lib, clean_env, mld):
             try:
                 assert_same(got, want, pb)
             except AssertionError as e:
-                raise AssertionError("maxLengthDel %d, haplotypes up to %d bp, %r, launches %r: %s" % (mld, bound, env, capi.launch_log(), str(e)[:300]))
+                raise AssertionError("maxLengthDel %d, %d-bp reads, haplotypes up to %d bp, %r, launches %r: %s" % (mld, L, bound, env, capi.launch_log(), str(e)[:300]))
     assert persistent_multi_round >= 20, persistent_multi_round          # the case this test exists for did occur
 
 
