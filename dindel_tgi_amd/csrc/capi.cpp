@@ -137,7 +137,7 @@ size_t lds_layout(int K, int Dt, int Lmax, int n_qual, int waves, bool gbt, int 
 int reg_limited_waves_per_cu(int K, int Dt, bool gbt, int G = 1)
 {
     (void)G;
-    if (Dt > 12) return 4;                        // the D = 32 build: one wave per SIMD
+    if (Dt > 12) return K <= 3 ? 12 : (K <= 6 ? 8 : 4);   // the D = 32 build keeps a lane's own positions only: 125-144 registers up to K = 3, <= 244 up to K = 6
     if (const char *e = getenv("DD_REG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) return v; }   // A/B builds with another occupancy
     if (K <= 2) return (Dt <= 7 || gbt) ? 12 : 8;
     if (K == 3) return (gbt && Dt <= 7) ? 12 : ((gbt || Dt <= 7) ? 8 : 4);      // round 3: the D = 6 scratch build is held to 168 VGPRs (3 waves/SIMD)

@@ -188,7 +188,7 @@ template <> struct BtWord<8> { typedef uint64_t type; };
 // D = 6 scratch build at 3 waves/SIMD (168 VGPRs, a few spills outside the sweeps) gains 10-12 % (231.7 -> 207.2 ms per 3,000 windows of
 // 160-bp haplotypes); the D = 11 one loses 14 % to its spills and stays at 2, as does K = 4.
 #ifndef DD_MIN_WAVES_PER_SIMD
-#define DD_MIN_WAVES_PER_SIMD(K, D, GBT, G) ((D) > 12 ? 1 : (K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : ((((K) <= 5 || (G) == 2) && (GBT)) ? 2 : 1))
+#define DD_MIN_WAVES_PER_SIMD(K, D, GBT, G) ((D) > 12 ? ((K) <= 3 ? 3 : (K) <= 6 ? 2 : 1) : (K) <= 2 ? (((D) <= 7 || (GBT)) ? 3 : 2) : ((K) == 3 && (D) <= 7 && (GBT)) ? 3 : ((((K) <= 5 || (G) == 2) && (GBT)) ? 2 : 1))
 #endif
 // GBT = back-pointers in a per-wave HBM scratch tile instead of LDS: for read length x haplotype length
 // combinations whose tile would leave a CU with too few wavefronts (or not fit its 160 KiB at all).  The
@@ -1466,7 +1466,7 @@ hipError_t launch_hmm_d12(int K, bool gbt, int build, const KernelArgs &A, dim3 
 
 #if DD_INST_D == 0 || DD_INST_D == 32
 // maxLengthDel 12..31 (the reference takes any --maxLengthIndel, DInDel.cpp:4157): one D = 32 build per K = 1..9 (7 bits of back-pointer per
-// position: 63 bits), whole wavefronts, scratch back-pointers, register-lean form, one wave per SIMD — built to be correct, not fast.
+// position: 63 bits), whole wavefronts, scratch back-pointers, register-lean form with the jump candidates in a run-time loop (no spilled register), 3 / 2 / 1 waves per SIMD for K <= 3 / <= 6 / <= 9.
 hipError_t launch_hmm_d32(int K, const KernelArgs &A, dim3 g, int waves, size_t lds, hipStream_t st)
 {
     switch (K) {
