@@ -14,7 +14,10 @@ tests/test_gpu_persistent_rounds.py is the run-time check).
 
 Reports every basic block in which a VGPR spill store / reload (v_accvgpr_write_b32 aN, vM / v_accvgpr_read_b32 / scratch_store / scratch_load)
 stands between the block's label and the instruction of the same block that switches lanes back on (`s_or_b64 exec, exec, ...`,
-`s_mov_b64 exec, ...`, `s_or_saveexec_b64`, ...), with nothing but scalar code around it.  Exit status 1 if any kernel has one."""
+`s_mov_b64 exec, ...`, `s_or_saveexec_b64`, ...), with nothing but scalar code around it (check), and every spill store that stands inside a
+straight-line `s_and_saveexec_b64 ... s_or_b64 exec, exec` region without the region having written its source (check_regions: the second form the
+fault took, two instructions in front of the restore and no label in between).  Exit status 1 if any kernel has one.  It knows these two forms, not
+the fault in general: DESIGN.md 4d."""
 import re
 import sys
 
