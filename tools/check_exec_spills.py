@@ -17,7 +17,8 @@ stands between the block's label and the instruction of the same block that swit
 `s_mov_b64 exec, ...`, `s_or_saveexec_b64`, ...), with nothing but scalar code around it (check), and every spill store that stands inside a
 straight-line `s_and_saveexec_b64 ... s_or_b64 exec, exec` region without the region having written its source (check_regions: the second form the
 fault took, two instructions in front of the restore and no label in between).  Exit status 1 if any kernel has one.  It knows these two forms, not
-the fault in general: DESIGN.md 4d."""
+the fault in general; `--broad` lists every spill store at a deeper exec nesting than its source's last write instead — candidates to
+read, false positives included, exit status 0."""
 import re
 import sys
 
@@ -164,7 +165,68 @@ def check_regions(body):
     return found
 
 
+def broad_scan(body):
+    """--broad: every spill store that runs at a deeper exec nesting than the last write of its source register (nesting counted along the straight
+    listing: `s_and_saveexec` / saved-and-narrowed `s_mov_b64 exec` open a level, `s_or_b64 exec, exec, <that mask>` closes it).  A superset of the two
+    checks with false positives (loops, values that only exist for the branch's lanes): a list of places to look at, not a verdict."""
+    stack, last_save, defd, pending = [], None, {}, []
+    for l in body:
+        s = l.split(";")[0].strip()
+        if not s or s.startswith("."):
+            continue
+        parts = s.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        a = args.replace(" ", "")
+        ops = [x.strip() for x in args.split(",")]
+        if op.endswith("saveexec_b64") and not a.endswith(",-1"):
+            stack.append(ops[0]); continue
+        if op == "s_mov_b64" and a.endswith(",exec"):
+            last_save = ops[0]; continue
+        if op == "s_mov_b64" and a.startswith("exec,"):
+            if ops[1] in stack:
+                while stack and stack[-1] != ops[1]: stack.pop()
+                if stack: stack.pop()
+            elif last_save is not None:
+                stack.append(last_save)
+            continue
+        if op == "s_or_b64" and a.startswith("exec,exec,"):
+            if ops[2] in stack:
+                while stack and stack[-1] != ops[2]: stack.pop()
+                stack.pop()
+            continue
+        d = len(stack)
+        # a store like that is harmless when its reload comes back inside the same branch (a register borrowed for the branch's own lanes):
+        # it stays a candidate only if the nesting drops below d before the slot is read again
+        for c in pending:
+            if c[2] is None and d < c[1]:
+                c[2] = True                                # the branch closed first
+        if op == "v_accvgpr_read_b32" or op.startswith("scratch_load"):
+            slot = ops[1] if op == "v_accvgpr_read_b32" else a.split("offset:")[-1] if "offset:" in a else "0"
+            for c in pending:
+                if c[2] is None and c[3] == slot:
+                    c[2] = False                           # read back inside the branch
+        if op == "v_accvgpr_write_b32" or op.startswith("scratch_store"):
+            if any(defd.get(v, 0) < d for v in vregs(ops[1])):
+                slot = ops[0] if op == "v_accvgpr_write_b32" else a.split("offset:")[-1] if "offset:" in a else "0"
+                pending.append([s, d, None, slot])
+            continue
+        if op.startswith(("v_", "ds_read", "global_load", "scratch_load", "buffer_load")) and not op.startswith(("v_cmp", "v_writelane", "v_readlane", "v_readfirstlane")):
+            for v in vregs(ops[0]):
+                defd[v] = d
+    return [(c[0], c[1]) for c in pending if c[2]]
+
+
 def main():
+    if "--broad" in sys.argv:
+        n = 0
+        for path in [x for x in sys.argv[1:] if x != "--broad"]:
+            for name, body in kernels(path):
+                f = broad_scan(body)
+                if f:
+                    n += 1
+                    print("%s: %s: %d spill store(s) deeper than their source's last write, e.g. %s (nesting %d)" % (path.split("/")[-2] if "/" in path else path, name, len(f), f[0][0], f[0][1]))
+        print("kernels listed by the broad scan: %d" % n)
+        return 0
     bad = 0
     for path in sys.argv[1:]:
         for name, body in kernels(path):
