@@ -721,6 +721,30 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
     if (rc) return rc;
     memset(out, 0, sizeof(*out));
     const int W = b->n_windows;
+    // pass 0: the folded builds (end states inside the generic candidate code, K <= 2 on the D = 6 build: +4.5 %) need every haplotype of their
+    // launch to leave the last position idle — 64 K >= Hs + 3, i.e. up to 61 / 125 bp of the 62 / 126 the tiling holds.  One 126-bp haplotype
+    // among thousands of shorter ones switched the fold off for all of them (the ragged leg's K = 2 launches).  When the haplotypes of exactly
+    // the tiling's full length are few, they go to the next tiling instead (promote[c]): they pay its extra lane-positions, the others fold.
+    bool promote[DD_N_HAP_CLASSES] = {false};
+    if (p && check_params(p) == DD_SUCCESS && pick_Dt(p->maxLengthDel + 1) == 6 && !getenv("DD_NO_FOLD") && !getenv("DD_NO_PROMOTE")) {
+        int64_t n_fold[DD_N_HAP_CLASSES] = {0}, n_edge[DD_N_HAP_CLASSES] = {0};
+        for (int w = 0; w < W; w++) {
+            if (win_skip && win_skip[w]) continue;
+            for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
+                const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
+                const int c = hap_class_of(len < 1 ? 1 : (len > DD_MAX_HAP_LEN ? DD_MAX_HAP_LEN : len));
+                if (len == kHapClasses[c].bound) n_edge[c]++; else n_fold[c]++;
+            }
+        }
+        for (int c = 0; c + 1 < DD_N_HAP_CLASSES; c++) {
+            int G0 = 1, K0 = 1, G1 = 1, K1 = 1;
+            if (!pick_tiling(kHapClasses[c].bound, 6, G0, K0) || !pick_tiling(kHapClasses[c + 1].bound, 6, G1, K1)) continue;
+            if (G0 != 1 || K0 > 2 || n_edge[c] == 0) continue;                      // only the tilings that have a folded build
+            const double extra = ((double)K1 / G1) / ((double)K0 / G0) - 1.0;      // what a promoted haplotype pays
+            promote[c] = (double)n_edge[c] * extra < 0.045 * (double)n_fold[c];
+        }
+    }
+    auto cls = [&](int len) { const int c = hap_class_of(len); return (promote[c] && len == kHapClasses[c].bound) ? c + 1 : c; };
     // pass 1: haplotype class maxima (the read thresholds depend on the class' longest haplotype)
     int hmax[DD_N_HAP_CLASSES] = {0};
     bool any_skipped = false;
@@ -729,7 +753,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
         for (int64_t h = b->win_hap_off[w]; h < b->win_hap_off[w + 1]; h++) {
             const int len = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
             if (len > DD_MAX_HAP_LEN) return fail(DD_ERR_UNSUPPORTED, "haplotype longer than 766 in a window that is not flagged in win_skip");
-            const int c = hap_class_of(len < 1 ? 1 : len);
+            const int c = cls(len < 1 ? 1 : len);
             if (len > hmax[c]) hmax[c] = len;
         }
     }
@@ -755,7 +779,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
         unsigned seen = 0;                                    // tilings of this window already handled
         for (int64_t h = h0; h < h1; h++) {
             const int hl = b->hap_seq_off[h + 1] - b->hap_seq_off[h];
-            const int c = hap_class_of(hl < 1 ? 1 : hl);
+            const int c = cls(hl < 1 ? 1 : hl);
             if (seen & (1u << c)) continue;
             seen |= 1u << c;
             int cnt[DD_N_READ_CLASSES] = {0}, mx[DD_N_READ_CLASSES] = {0};
@@ -779,7 +803,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
                 Acc &a = acc[(size_t)c * DD_N_READ_CLASSES + k];
                 for (int64_t g = h; g < h1; g++) {
                     const int gl = b->hap_seq_off[g + 1] - b->hap_seq_off[g];
-                    if (hap_class_of(gl < 1 ? 1 : gl) != c) continue;
+                    if (cls(gl < 1 ? 1 : gl) != c) continue;
                     a.haps.push_back((int32_t)g);
                     if (gl > a.max_hap) a.max_hap = gl;
                 }
