@@ -217,9 +217,15 @@ def ragged_leg(params, device, windows=2400, steps=3):
         hw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_hap_off"]))
         rw = np.repeat(np.arange(pb.n_windows), np.diff(pb.a["win_read_off"]))
         launches = []
+        ci_of_hap = lambda mh: int(np.searchsorted(capi.HAP_CLASS_BOUNDS, mh, side="left"))
         for rec in log:
             ci = int(np.searchsorted(capi.HAP_CLASS_BOUNDS, rec["max_hap"], side="left"))    # the launch's lane tiling = haplotype-length class
             hsel = (hl > (capi.HAP_CLASS_BOUNDS[ci - 1] if ci else 0)) & (hl <= capi.HAP_CLASS_BOUNDS[ci])
+            # the haplotypes of exactly the tiling's full length may run apart (capi.cpp build_launch_classes: the others then take the folded build)
+            apart = any(q is not rec and ci_of_hap(q["max_hap"]) == ci and (q["min_read"], q["max_read"] > 160) == (rec["min_read"], rec["max_read"] > 160)
+                        and (q["max_hap"] == capi.HAP_CLASS_BOUNDS[ci]) != (rec["max_hap"] == capi.HAP_CLASS_BOUNDS[ci]) for q in log)
+            if apart:
+                hsel &= (hl == capi.HAP_CLASS_BOUNDS[ci]) if rec["max_hap"] == capi.HAP_CLASS_BOUNDS[ci] else (hl < capi.HAP_CLASS_BOUNDS[ci])
             rsel = (rl >= rec["min_read"]) & (rl <= rec["max_read"])
             # read classes 0 / 1 of a tiling split the WINDOWS by their longest read up to 160 bp (capi.cpp build_launch_classes): a launch
             # that starts at 1 bp owns the windows whose longest such read is above the longest read of the tiling's shorter launch

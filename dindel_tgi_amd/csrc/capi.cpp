@@ -724,7 +724,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
     // pass 0: the folded builds (end states inside the generic candidate code, K <= 2 on the D = 6 build: +4.5 %) need every haplotype of their
     // launch to leave the last position idle — 64 K >= Hs + 3, i.e. up to 61 / 125 bp of the 62 / 126 the tiling holds.  One 126-bp haplotype
     // among thousands of shorter ones switched the fold off for all of them (the ragged leg's K = 2 launches).  When the haplotypes of exactly
-    // the tiling's full length are few, they go to the next tiling instead (promote[c]): they pay its extra lane-positions, the others fold.
+    // the tiling's full length are few, they run apart (promote[c]): launches of their own, same tiling, not folded; the others fold.
     bool promote[DD_N_HAP_CLASSES] = {false};
     if (p && check_params(p) == DD_SUCCESS && pick_Dt(p->maxLengthDel + 1) == 6 && !getenv("DD_NO_FOLD") && !getenv("DD_NO_PROMOTE")) {
         int64_t n_fold[DD_N_HAP_CLASSES] = {0}, n_edge[DD_N_HAP_CLASSES] = {0};
@@ -736,17 +736,23 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
                 if (len == kHapClasses[c].bound) n_edge[c]++; else n_fold[c]++;
             }
         }
-        for (int c = 0; c + 1 < DD_N_HAP_CLASSES; c++) {
-            int G0 = 1, K0 = 1, G1 = 1, K1 = 1;
-            if (!pick_tiling(kHapClasses[c].bound, 6, G0, K0) || !pick_tiling(kHapClasses[c + 1].bound, 6, G1, K1)) continue;
-            if (G0 != 1 || K0 > 2 || n_edge[c] == 0) continue;                      // only the tilings that have a folded build
-            const double extra = ((double)K1 / G1) / ((double)K0 / G0) - 1.0;      // what a promoted haplotype pays
-            promote[c] = (double)n_edge[c] * extra < 0.045 * (double)n_fold[c];
+        int used = 0, moved = 0;
+        for (int c = 0; c < DD_N_HAP_CLASSES; c++) used += (n_fold[c] + n_edge[c]) > 0 ? 1 : 0;
+        for (int c = 0; c < DD_N_HAP_CLASSES; c++) {
+            int G0 = 1, K0 = 1;
+            if (!pick_tiling(kHapClasses[c].bound, 6, G0, K0)) continue;
+            if (G0 != 1 || K0 > 2 || n_edge[c] == 0 || n_fold[c] == 0) continue;   // only the tilings that have a folded build
+            // the full-length haplotypes get launches of their own (same tiling, not folded: they cost what they cost before); worth it when the
+            // launch they leave behind is the bigger part — a small launch fills the chip badly
+            promote[c] = n_edge[c] * 4 < n_fold[c] && (used + moved + 1) * DD_N_READ_CLASSES <= DD_N_HAP_CLASSES * DD_N_READ_CLASSES;
+            moved += promote[c] ? 1 : 0;
         }
     }
-    auto cls = [&](int len) { const int c = hap_class_of(len); return (promote[c] && len == kHapClasses[c].bound) ? c + 1 : c; };
+    // internal class ids: 0 .. N-1 the tilings, N + c the full-length haplotypes of tiling c when they run apart
+    constexpr int NC = 2 * DD_N_HAP_CLASSES;
+    auto cls = [&](int len) { const int c = hap_class_of(len); return (promote[c] && len == kHapClasses[c].bound) ? DD_N_HAP_CLASSES + c : c; };
     // pass 1: haplotype class maxima (the read thresholds depend on the class' longest haplotype)
-    int hmax[DD_N_HAP_CLASSES] = {0};
+    int hmax[NC] = {0};
     bool any_skipped = false;
     for (int w = 0; w < W; w++) {
         if (win_skip && win_skip[w]) { any_skipped = any_skipped || b->win_hap_off[w + 1] > b->win_hap_off[w]; continue; }
@@ -757,9 +763,9 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
             if (len > hmax[c]) hmax[c] = len;
         }
     }
-    int bound[DD_N_HAP_CLASSES][DD_N_READ_CLASSES];          // upper read length of each interval of each tiling
+    int bound[NC][DD_N_READ_CLASSES];                        // upper read length of each interval of each tiling
     const bool one_read_class = getenv("DD_LENGTH_CLASSES") && !strcmp(getenv("DD_LENGTH_CLASSES"), "k");   // A/B: haplotype classes only
-    for (int c = 0; c < DD_N_HAP_CLASSES; c++) {
+    for (int c = 0; c < NC; c++) {
         int T = hmax[c] > 0 ? lds_read_threshold(p, hmax[c], b->n_qual) : 0;
         if (getenv("DD_READ_BOUND")) T = atoi(getenv("DD_READ_BOUND"));                                    // A/B only
         if (T < 1 || T >= 160) T = 0;
@@ -770,7 +776,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
     auto read_class = [&](int c, int len) { return len <= bound[c][0] ? 0 : (len <= bound[c][1] ? 1 : 2); };
     // pass 2: per window, which (tiling, interval) launches its haplotypes take part in
     struct Acc { std::vector<int32_t> haps; int max_hap = 0, max_read = 0, max_reads = 0; int64_t sum_reads = 0, n_win = 0, sum_len = 0; };
-    std::vector<Acc> acc((size_t)DD_N_HAP_CLASSES * DD_N_READ_CLASSES);
+    std::vector<Acc> acc((size_t)NC * DD_N_READ_CLASSES);
     std::vector<int32_t> skipped;                             // haplotypes of skipped windows: marked by the first launch
     for (int w = 0; w < W; w++) {
         const int64_t h0 = b->win_hap_off[w], h1 = b->win_hap_off[w + 1], q0 = b->win_read_off[w], q1 = b->win_read_off[w + 1];
@@ -827,7 +833,7 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
         L.list_len = (int32_t)a.haps.size();
         if (list) memcpy(list + off, a.haps.data(), a.haps.size() * sizeof(int32_t));
         off += L.list_len;
-        L.hap_class = c;
+        L.hap_class = c % DD_N_HAP_CLASSES;
         L.max_hap_len = a.max_hap > 0 ? a.max_hap : 1;
         L.min_read_len = k == 2 ? bound[c][1] + 1 : 1;       // (class 1 = the windows with a read beyond T: all their reads up to 160 bp)
         L.max_read_len = a.max_read > 0 ? a.max_read : 1;
@@ -836,10 +842,11 @@ static int build_launch_classes(const dd_batch *b, const uint8_t *win_skip, cons
         L.avg_read_len = a.sum_reads ? (int32_t)(a.sum_len / a.sum_reads) : 0;
     };
     bool first = true;
-    for (int c = 0; c < DD_N_HAP_CLASSES; c++)
+    for (int c = 0; c < NC; c++)
         for (int k = 0; k < DD_N_READ_CLASSES; k++) {
             Acc &a = acc[(size_t)c * DD_N_READ_CLASSES + k];
             if (a.haps.empty()) continue;
+            if (out->n_launches >= DD_N_HAP_CLASSES * DD_N_READ_CLASSES) return fail(DD_ERR_UNSUPPORTED, "more launch classes than dd_length_classes holds");
             emit(c, k, a, first ? &skipped : nullptr);
             first = false;
         }

@@ -211,7 +211,7 @@ def test_launch_plan_rules(lib, monkeypatch):
 
 def test_full_length_haplotypes_leave_the_folded_launch(lib, monkeypatch):
     """The folded builds (K <= 2, D = 6) need 64 K >= Hs + 3 for every haplotype of their launch: a few haplotypes of exactly 126 (62) bp go to a launch of
-    their own (listed under the next tiling) so that the thousands of shorter ones keep the fold; many of them stay where they are."""
+    their own (same tiling, not folded) so that the thousands of shorter ones keep the fold; many of them stay where they are."""
     rng = np.random.default_rng(9)
     def batch(n_short, n_full, full=126):
         wins = []
@@ -228,16 +228,16 @@ def test_full_length_haplotypes_leave_the_folded_launch(lib, monkeypatch):
         assert lib.dd_build_length_classes(C.byref(b), None, C.byref(p) if params else None, lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0
         return [(cls.launch[i].hap_class, cls.launch[i].list_len, cls.launch[i].max_hap_len) for i in range(cls.n_launches)]
     pb = batch(200, 3)
-    assert classes(pb) == [(3, 200, 125), (4, 3, 126)]                    # the three 126-bp haplotypes run apart (still K = 2: their launch's longest is 126)
+    assert classes(pb) == [(3, 200, 125), (3, 3, 126)]                    # the three 126-bp haplotypes run apart
     monkeypatch.setenv("DD_NO_PROMOTE", "1")
     assert classes(pb) == [(3, 203, 126)]
     monkeypatch.delenv("DD_NO_PROMOTE")
-    assert classes(batch(200, 60)) == [(3, 260, 126)]                      # too many to move: 60 x 25 % more lane-positions > 4.5 % of 200
+    assert classes(batch(200, 60)) == [(3, 260, 126)]                      # too many to move (more than a quarter of the others)
     assert classes(pb, params=False) == [(3, 203, 126)]                    # no parameters, no plan: nothing moves
     p10 = capi.params_cli_defaults(); p10.maxLengthDel = 10                # the D = 11 build has no folded variant on the plan's path
     b = pb.ctypes_batch(); cls = capi.dd_length_classes(); lst = np.zeros(pb.n_haps * capi.N_READ_CLASSES, np.int32)
     assert lib.dd_build_length_classes(C.byref(b), None, C.byref(p10), lst.ctypes.data_as(capi.c_i32p), C.byref(cls)) == 0 and cls.n_launches == 1
-    assert classes(batch(300, 2, full=62)) == [(1, 300, 61), (2, 2, 62)]   # K = 1 likewise
+    assert classes(batch(300, 2, full=62)) == [(1, 300, 61), (1, 2, 62)]   # K = 1 likewise
 
 
 def test_length_classes_and_library_tables_on_the_host(lib):
