@@ -21,8 +21,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i --output-format csv -- python3 $R/bench.py --ragged-only --steps 2 > $OUT/pmc_$i.json 2> $OUT/pmc_$i.log
   echo "pmc pass $i done"
 done
-python3 $R/tools/pmc_summary.py $OUT "dd_hmm_kernel<2, 6, false, false, 0, 1>" > $OUT/pmc_k2_lds.json
+# (since the full-length haplotypes run apart, the leg's K = 2 launches are the FOLDED builds <2, 6, *, true, 0, 1>)
+python3 $R/tools/pmc_summary.py $OUT "dd_hmm_kernel<2, 6, false, true, 0, 1>" > $OUT/pmc_k2_lds.json
 python3 $R/tools/pmc_summary.py $OUT "dd_hmm_kernel<5, 6, true, false, 0, 2>" > $OUT/pmc_k5_half.json
-python3 $R/tools/pmc_summary.py $OUT "dd_hmm_kernel<2, 6, true, false, 0, 1>" > $OUT/pmc_k2_scratch.json
+python3 $R/tools/pmc_summary.py $OUT "dd_hmm_kernel<2, 6, true, true, 0, 1>" > $OUT/pmc_k2_scratch.json
 rm -rf $OUT/trace $OUT/pmc_[0-9] $OUT/*.log $OUT/pmc_[0-9].json
 head -c 600 $OUT/pmc_k5_half.json
